@@ -1,0 +1,208 @@
+#!/usr/bin/env python3
+"""bench.py -- primary Mrays/s and frame ms of the ray-casting hot path on MI355X.
+
+    python bench.py --gpus N --steps K --warmup W [--mode frames|bands] [--sequence]
+                    [--config c3_3840x2160_n1024] [--variant tiled|literal] [--no-cpu]
+
+A step is one pass of the hot path (rc_render -> the draw kernel) over one frame of the
+workload, inputs (scene arrays, sine tables) already resident in HBM.  Default workload:
+3840x2160, 1024 spheres, camera (0,0,20) -- the configuration BASELINE.json's metric names.
+
+Multi-GPU (launched by torch.distributed.run, one rank per GPU):
+  --mode frames (default)  whole frames are sharded over ranks, no data-path collective;
+                           per-GPU work is fixed as N grows -> "scaling": "weak".
+  --mode bands             ONE frame per step is split into row bands, every rank renders its
+                           band and the bands are gathered on rank 0 over RCCL ("strong").
+
+One JSON line is printed by rank 0.  `roofline` prices the dominant kernel (the draw kernel)
+against the FP32 vector peak with ALGORITHMIC work = 7 FLOP per ray-sphere test;
+`cpu_baseline` times the CPU oracle (a port of the reference's per-pixel function) on this
+box's host cores on a bounded sample of the same workload (rank 0, N=1 only).
+"""
+import argparse
+import ctypes as C
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+from cudaraytracing_amd import abi, configs  # noqa: E402
+from cudaraytracing_amd.host import Camera, DeviceBuffer, generate_scene  # noqa: E402
+
+FP32_VECTOR_PEAK_TFLOPS = 157.3     # MI355X vector FP32 peak (256 CU x 4 SIMD x 64 FLOP/clk x 2.4 GHz)
+HBM_PEAK_GBS = 8000.0
+FLOP_PER_TEST = 7                   # b' = v.d (3 mul + 2 add), disc' = b'b' - c (1 mul + 1 sub)
+
+
+def parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=200)
+    ap.add_argument("--warmup", type=int, default=20)
+    ap.add_argument("--config", default="c3_3840x2160_n1024", choices=sorted(configs.CONFIGS))
+    ap.add_argument("--mode", default="frames", choices=["frames", "bands"])
+    ap.add_argument("--sequence", action="store_true", help="animate the camera along the 300-frame path")
+    ap.add_argument("--variant", default="tiled", choices=["tiled", "tiled2", "literal"])
+    ap.add_argument("--no-cpu", action="store_true", help="skip the cpu_baseline leg")
+    ap.add_argument("--cpu-rows", type=int, default=0, help="rows of the frame the CPU baseline renders (0 = auto)")
+    return ap.parse_args()
+
+
+def cpu_baseline(cfg, threads):
+    """Oracle (port of kernel.cu:21-112) on the host cores, bounded sample of the same frame."""
+    from oracle import binding as ob     # the checker, used here only as the timed CPU baseline
+    w, h, n = cfg["width"], cfg["height"], cfg["n"]
+    pos, rad, col = ob.generate_scene(n, cfg["seed"])
+    cam = ob.camera_data(cfg["position"], cfg["rotation"], w, h)
+    # ~6.4 ns per test per core: pick rows so the sample is ~20 core-seconds of work
+    rows = int(min(h, max(threads, 20.0 / (6.4e-9 * w * max(n, 1)))))
+    rows = max(threads, rows - rows % threads)
+    y0 = (h - rows) // 2
+    ob.render(pos, rad, col, cam, w, min(rows, 4 * threads), y_offset=y0, full_height=h, threads=threads)  # warm
+    t0 = time.perf_counter()
+    ob.render(pos, rad, col, cam, w, rows, y_offset=y0, full_height=h, threads=threads)
+    dt = time.perf_counter() - t0
+    return {
+        "value": w * rows / dt / 1e6, "unit": "Mrays/s", "cores": threads, "kind": "port",
+        "sample": f"{rows} centre rows of one {w}x{h} frame, {n} spheres ({w * rows * n / 1e9:.2f} G tests) in {dt:.2f} s",
+        "ns_per_test_per_core": dt * threads / (w * rows * max(n, 1)) * 1e9,
+    }
+
+
+def main():
+    args = parse()
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if world != args.gpus and world != 1:
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
+    if args.gpus > 1 and world == 1:
+        raise SystemExit("for --gpus N>1 launch with: python -m torch.distributed.run --nproc-per-node N bench.py --gpus N ...")
+
+    import torch
+    import torch.distributed as dist
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs a GPU (the HIP path has no CPU fallback)")
+    torch.cuda.set_device(local_rank)
+    lib = abi.load()
+    abi.check(lib.rc_set_device(local_rank), "rc_set_device")
+    if world > 1:
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+
+    cfg = configs.CONFIGS[args.config]
+    w, h, n = cfg["width"], cfg["height"], cfg["n"]
+    variant = {"tiled": abi.VARIANT_TILED, "tiled2": abi.VARIANT_TILED2, "literal": abi.VARIANT_LITERAL}[args.variant]
+
+    # scene resident in HBM before the timed region (SceneManager.cpp:17-24)
+    pos, rad, col = generate_scene(n, cfg["seed"])
+    bufs = []
+    for a in (pos, rad, col):
+        b = DeviceBuffer(max(a.nbytes, 4))
+        b.upload(a)
+        bufs.append(b)
+    scene = abi.RcScene()
+    scene.sphere_num = n
+    scene.position, scene.radius, scene.color = (b.ptr.value for b in bufs)
+    cam = Camera(w, h)
+    cam.position, cam.rotation = cfg["position"], cfg["rotation"]
+    scene.cam = cam.get_data()
+
+    if args.mode == "bands" and world > 1:
+        y0, y1 = configs.band_rows(h, world, rank)
+    else:
+        y0, y1 = 0, h
+    rows = y1 - y0
+    # the frame lives in a torch tensor so that the band gather can use torch.distributed
+    frame = torch.empty((rows, w, 4), dtype=torch.float32, device="cuda")
+    screen = abi.RcScreen(frame.data_ptr(), w, rows, w * 16)
+    stream = torch.cuda.current_stream().cuda_stream
+    opts = abi.RcOpts(y_offset=y0, full_height=h, variant=variant, stream=stream)
+    gathered = None
+    if args.mode == "bands" and world > 1 and rank == 0:
+        gathered = [torch.empty((configs.band_rows(h, world, r)[1] - configs.band_rows(h, world, r)[0], w, 4),
+                                dtype=torch.float32, device="cuda") for r in range(world)]
+
+    def step(i):
+        if args.sequence:
+            f = (i * (world if args.mode == "frames" else 1) + (rank if args.mode == "frames" else 0)) % configs.SEQUENCE_FRAMES
+            cam.position, cam.rotation = configs.sequence_camera(f)
+            scene.cam = cam.get_data()                     # SceneManager::UpdateCamera
+        abi.check(lib.rc_render(C.byref(screen), C.byref(scene), C.byref(opts)), "rc_render")
+        if args.mode == "bands" and world > 1:
+            dist.gather(frame, gathered, dst=0)
+
+    def fence():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for i in range(args.warmup):
+        step(i)
+    fence()
+    ev0, ev1 = C.c_void_p(), C.c_void_p()
+    abi.check(lib.rc_event_create(C.byref(ev0)))
+    abi.check(lib.rc_event_create(C.byref(ev1)))
+    t0 = time.perf_counter()
+    abi.check(lib.rc_event_record(ev0, stream))
+    for i in range(args.steps):
+        step(args.warmup + i)
+    abi.check(lib.rc_event_record(ev1, stream))
+    fence()
+    dt = time.perf_counter() - t0
+    ev_ms = C.c_float()
+    abi.check(lib.rc_event_elapsed_ms(ev0, ev1, C.byref(ev_ms)))
+
+    t = torch.tensor([dt], dtype=torch.float64, device="cuda")
+    if world > 1:
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+    dt_max = float(t.item())
+
+    frames_total = args.steps * (world if args.mode == "frames" else 1)
+    value = w * h * frames_total / dt_max / 1e6
+    kernel_ms = ev_ms.value / args.steps           # HIP events on the launch stream, this rank
+    tests = w * rows * n
+    achieved_tflops = FLOP_PER_TEST * tests / (kernel_ms * 1e-3) / 1e12
+
+    if rank == 0:
+        cu, khz, lds = C.c_int(), C.c_int(), C.c_size_t()
+        abi.check(lib.rc_device_info(local_rank, C.byref(cu), C.byref(khz), C.byref(lds)))
+        name = C.create_string_buffer(256)
+        abi.check(lib.rc_device_name(local_rank, name, 256))
+        out = {
+            "metric": "primary Mrays/sec at %dx%d, %d spheres" % (w, h, n),
+            "value": value, "unit": "Mrays/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": dt_max / args.steps * 1e3, "higher_is_better": True,
+            "scaling": "weak" if args.mode == "frames" else "strong",
+            "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "config": {"workload": args.config, "width": w, "height": h, "spheres": n, "mode": "REF",
+                       "variant": args.variant, "sharding": args.mode, "camera": "sequence" if args.sequence else "static",
+                       "device": name.value.decode(), "compute_units": cu.value, "clock_mhz": khz.value / 1e3},
+            "frame_ms": kernel_ms,
+            "roofline": {
+                "bound": "valu_fp32", "achieved": achieved_tflops, "peak": FP32_VECTOR_PEAK_TFLOPS, "unit": "TFLOP/s",
+                "frac": achieved_tflops / FP32_VECTOR_PEAK_TFLOPS, "traffic": None,
+                "kernel": "rc_draw_tiled<4>" if args.variant == "tiled" else args.variant,
+                "kernel_ms": kernel_ms, "flop_per_test": FLOP_PER_TEST, "tests_per_launch": tests,
+                "ref_equiv_tflops_21flop": 21 * tests / (kernel_ms * 1e-3) / 1e12,
+                "hbm_write_gbs": 16.0 * w * rows / (kernel_ms * 1e-3) / 1e9, "hbm_peak_gbs": HBM_PEAK_GBS,
+            },
+        }
+        if not args.no_cpu and world == 1:
+            threads = int(os.environ.get("OMP_NUM_THREADS", "0")) or min(os.cpu_count() or 1, 16)
+            out["cpu_baseline"] = cpu_baseline(cfg, threads)
+            out["gpu_over_cpu"] = value / out["cpu_baseline"]["value"]
+        else:
+            out["cpu_baseline"] = None
+        print(json.dumps(out), flush=True)
+
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

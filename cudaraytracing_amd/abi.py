@@ -1,0 +1,107 @@
+"""ctypes binding of librc_hip.so (include/rc_abi.h).
+
+Plumbing for tests and bench.py only: the product is the shared library.  There is no
+CPU fallback -- if the library is missing, loading fails loudly.
+"""
+import ctypes as C
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "librc_hip.so")
+
+RC_OK = 0
+RC_EINVAL = -100001
+
+VARIANT_AUTO = 0
+VARIANT_LITERAL = 1
+VARIANT_TILED = 2
+VARIANT_TILED2 = 3
+
+
+class RcVec3(C.Structure):
+    _fields_ = [("x", C.c_float), ("y", C.c_float), ("z", C.c_float)]
+
+
+class RcCamera(C.Structure):
+    _fields_ = [("aspect", C.c_float), ("fov", C.c_float), ("position", RcVec3),
+                ("forward", RcVec3), ("up", RcVec3), ("right", RcVec3)]
+
+
+class RcScene(C.Structure):
+    _fields_ = [("sphere_num", C.c_int), ("position", C.c_void_p), ("radius", C.c_void_p),
+                ("color", C.c_void_p), ("cam", RcCamera)]
+
+
+class RcScreen(C.Structure):
+    _fields_ = [("surface", C.c_void_p), ("width", C.c_int), ("height", C.c_int),
+                ("pitch", C.c_size_t)]
+
+
+class RcOpts(C.Structure):
+    _fields_ = [("y_offset", C.c_int), ("full_height", C.c_int), ("variant", C.c_int),
+                ("reserved0", C.c_int), ("stream", C.c_void_p), ("rgba8", C.c_void_p),
+                ("rgba8_pitch", C.c_size_t), ("rgba8_flip", C.c_int), ("reserved1", C.c_int)]
+
+
+assert C.sizeof(RcVec3) == 12 and C.sizeof(RcCamera) == 56
+assert C.sizeof(RcScene) == 88 and C.sizeof(RcScreen) == 24
+
+# every symbol include/rc_abi.h declares: name -> (restype, argtypes)
+SYMBOLS = {
+    "rc_render": (C.c_int, [C.POINTER(RcScreen), C.POINTER(RcScene), C.POINTER(RcOpts)]),
+    "rc_to_rgba8": (C.c_int, [C.POINTER(RcScreen), C.c_void_p, C.c_size_t, C.c_int, C.c_void_p]),
+    "rc_device_count": (C.c_int, [C.POINTER(C.c_int)]),
+    "rc_device_name": (C.c_int, [C.c_int, C.c_char_p, C.c_size_t]),
+    "rc_set_device": (C.c_int, [C.c_int]),
+    "rc_device_info": (C.c_int, [C.c_int, C.POINTER(C.c_int), C.POINTER(C.c_int), C.POINTER(C.c_size_t)]),
+    "rc_malloc_pitch": (C.c_int, [C.POINTER(C.c_void_p), C.POINTER(C.c_size_t), C.c_size_t, C.c_size_t]),
+    "rc_malloc": (C.c_int, [C.POINTER(C.c_void_p), C.c_size_t]),
+    "rc_free": (C.c_int, [C.c_void_p]),
+    "rc_memset": (C.c_int, [C.c_void_p, C.c_int, C.c_size_t, C.c_void_p]),
+    "rc_upload": (C.c_int, [C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p]),
+    "rc_download_2d": (C.c_int, [C.c_void_p, C.c_size_t, C.c_void_p, C.c_size_t, C.c_size_t, C.c_size_t, C.c_void_p]),
+    "rc_sync": (C.c_int, [C.c_void_p]),
+    "rc_event_create": (C.c_int, [C.POINTER(C.c_void_p)]),
+    "rc_event_record": (C.c_int, [C.c_void_p, C.c_void_p]),
+    "rc_event_elapsed_ms": (C.c_int, [C.c_void_p, C.c_void_p, C.POINTER(C.c_float)]),
+    "rc_event_destroy": (C.c_int, [C.c_void_p]),
+    "rc_camera_data": (None, [C.POINTER(RcVec3), C.POINTER(RcVec3), C.c_int, C.c_int, C.POINTER(RcCamera)]),
+    "rc_generate_scene": (None, [C.c_uint32, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p]),
+    "rc_write_ppm": (C.c_int, [C.c_char_p, C.c_void_p, C.c_size_t, C.c_int, C.c_int]),
+    "rc_last_error_string": (C.c_char_p, []),
+    "rc_version": (C.c_char_p, []),
+    # the source-level drop-in (kernel.cu:114-115); C++ by-value convention, so it is only
+    # checked for presence here and exercised by the C++ caller in tests/
+    "execute_kernel": (None, None),
+}
+
+_lib = None
+
+
+class RcError(RuntimeError):
+    pass
+
+
+def load():
+    """Load librc_hip.so (no GPU needed to load; compute calls need one)."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise RcError(
+            f"{LIB_PATH} is missing: build it with `python -m cudaraytracing_amd.build` "
+            "(there is no CPU fallback)")
+    lib = C.CDLL(LIB_PATH)
+    for name, (restype, argtypes) in SYMBOLS.items():
+        fn = getattr(lib, name)   # AttributeError if the symbol is not exported
+        if argtypes is not None:
+            fn.restype = restype
+            fn.argtypes = argtypes
+    _lib = lib
+    return lib
+
+
+def check(rc, what="rc call"):
+    if rc != RC_OK:
+        msg = load().rc_last_error_string().decode(errors="replace")
+        raise RcError(f"{what} failed ({rc}): {msg}")

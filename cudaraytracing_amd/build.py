@@ -1,0 +1,66 @@
+"""Builds librc_hip.so (HIP kernels + C ABI) for gfx950 with hipcc, in-tree.
+
+hipcc cross-compiles without a GPU.  The library is rebuilt only when a source is newer
+than the existing binary, so a tree that already holds the .so (the GPU box) builds nothing.
+"""
+import os
+import shutil
+import subprocess
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+_ROOT = os.path.dirname(_HERE)
+CSRC = os.path.join(_HERE, "csrc")
+LIB_PATH = os.path.join(_HERE, "librc_hip.so")
+CLI_PATH = os.path.join(_HERE, "rc_render")
+
+SOURCES = [os.path.join(CSRC, "rc_kernels.hip"), os.path.join(CSRC, "rc_host.hip")]
+HEADERS = [os.path.join(CSRC, "rc_kernels.h"), os.path.join(_ROOT, "include", "rc_abi.h")]
+
+# -ffp-contract=off: every product/sum of the exact path is a separately rounded binary32
+# operation; the filter's FMAs are written explicitly with __builtin_fmaf.
+HIPCC_FLAGS = [
+    "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-ffp-contract=off",
+    "-fno-fast-math", "-Wall", "-Wno-unused-result",
+    "-I" + os.path.join(_ROOT, "include"), "-I" + CSRC,
+]
+
+
+def _stale(target, deps):
+    if not os.path.exists(target):
+        return True
+    t = os.path.getmtime(target)
+    return any(os.path.exists(d) and os.path.getmtime(d) > t for d in deps)
+
+
+def hipcc_path():
+    p = shutil.which("hipcc") or "/opt/rocm/bin/hipcc"
+    if not os.path.exists(p):
+        raise RuntimeError("hipcc not found: cannot build librc_hip.so")
+    return p
+
+
+def build(force=False, verbose=False):
+    """Compile librc_hip.so and the rc_render CLI if missing or stale. Returns the .so path."""
+    if force or _stale(LIB_PATH, SOURCES + HEADERS):
+        cmd = [hipcc_path()] + HIPCC_FLAGS + ["-shared", "-o", LIB_PATH] + SOURCES
+        if verbose:
+            print(" ".join(cmd))
+        subprocess.run(cmd, check=True, cwd=_ROOT)
+    cli_src = os.path.join(CSRC, "host", "rc_render_main.cpp")
+    cli_deps = [cli_src, LIB_PATH] + [
+        os.path.join(CSRC, "host", h) for h in ("rc_camera.hpp", "rc_scene_manager.hpp", "rc_raycaster.hpp")
+    ]
+    if os.path.exists(cli_src) and (force or _stale(CLI_PATH, cli_deps)):
+        cmd = ["g++", "-O2", "-std=c++17", "-ffp-contract=off", "-I" + os.path.join(_ROOT, "include"),
+               "-I" + os.path.join(CSRC, "host"), cli_src, "-o", CLI_PATH,
+               "-L" + _HERE, "-lrc_hip", "-Wl,-rpath,$ORIGIN", "-lpthread"]
+        if verbose:
+            print(" ".join(cmd))
+        subprocess.run(cmd, check=True, cwd=_ROOT)
+    return LIB_PATH
+
+
+if __name__ == "__main__":
+    import sys
+    build(force="--force" in sys.argv, verbose=True)
+    print(LIB_PATH)

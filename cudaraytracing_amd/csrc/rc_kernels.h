@@ -1,0 +1,38 @@
+// rc_kernels.h -- kernel argument block and launchers shared by rc_kernels.hip / rc_host.hip.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stddef.h>
+#include <stdint.h>
+
+#define RC_LDS_CHUNK 2048   // spheres staged in LDS per pass (24 KiB of records + 2 KiB flags)
+
+enum { RC_KVARIANT_LITERAL = 1, RC_KVARIANT_TILED4 = 2, RC_KVARIANT_TILED2 = 3 };
+
+// Passed by value as the kernel parameter, as the reference passes Screen and Scene
+// (kernel.cu:69).  `rows` is the number of surface rows (a band of the frame); frame row of
+// surface row r is r + y_offset; sin_y is indexed by FRAME row.
+struct RcKernArgs {
+    void *surface;
+    size_t pitch;
+    int width;
+    int rows;
+    int y_offset;
+    int n;
+    const float *sin_x;      // [width]        sinf(fov * (x / width - 0.5))
+    const float *sin_y;      // [full_height]  sinf(fov * (y / full_height - 0.5))
+    const float *position;   // [3n]
+    const float *radius;     // [n]
+    const float *color;      // [3n]
+    void *rgba8;             // optional
+    size_t rgba8_pitch;
+    int rgba8_flip;
+    float aspect;
+    float ox, oy, oz;        // cam.position
+    float fx, fy, fz;        // cam.forward
+    float ux, uy, uz;        // cam.up
+    float rx, ry, rz;        // cam.right
+};
+
+hipError_t rc_launch_draw(const RcKernArgs &a, int variant, hipStream_t stream);
+hipError_t rc_launch_rgba8(const void *surface, size_t pitch, int width, int rows, void *out,
+                           size_t out_pitch, int flip, hipStream_t stream);

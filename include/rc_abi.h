@@ -1,0 +1,159 @@
+/*
+ * rc_abi.h -- C ABI of librc_hip.so, the MI355X (gfx950) ray-casting hot path.
+ *
+ * Plain C: pointers, sizes and POD structs only.  Every entry point cites the reference
+ * interface it replaces (paths relative to RayCasting/RayCasting/ of McThrok/CUDARayTracing).
+ *
+ * Conventions
+ *   - All rc_* functions return 0 on success or a negative value: -(hipError_t) for a HIP
+ *     failure, RC_EINVAL for a rejected argument.  They never exit() and never throw.
+ *     rc_last_error_string() describes the calling thread's last failure.
+ *   - rc_render()/execute_kernel() only ENQUEUE work (the reference launch at kernel.cu:123
+ *     is asynchronous and its caller synchronises at RayTracingKernel.cpp:18).
+ *   - The caller owns every buffer it passes, as in the reference (scene arrays:
+ *     SceneManager.cpp:17-24,49-51; surface: RayTracingKernel.cpp:93,100).
+ *   - Surface format: float RGBA, 16 bytes per pixel, row pitch >= 16*width bytes and a
+ *     multiple of 16 (kernel.cu:78,83,102-109; DXGI_FORMAT_R32G32B32A32_FLOAT,
+ *     RayTracingKernel.cpp:92-93).  Row 0 is the BOTTOM of the picture (kernel.cu:47).
+ */
+#ifndef RC_ABI_H
+#define RC_ABI_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define RC_OK 0
+#define RC_EINVAL (-100001)
+#define RC_ENOTBUILT (-100002)
+
+/* ---- argument structs: layout-identical PODs of the reference classes ---------------- */
+
+/* vec3.h:6-10 (12 bytes) */
+typedef struct rc_vec3 { float x, y, z; } rc_vec3;
+
+/* Camera.h:8-19 CameraData (56 bytes) */
+typedef struct rc_camera {
+    float aspect;
+    float fov;
+    rc_vec3 position;
+    rc_vec3 forward;
+    rc_vec3 up;
+    rc_vec3 right;
+} rc_camera;
+
+/* Scene.h:4-13 (88 bytes; position/radius/color are DEVICE pointers) */
+typedef struct rc_scene {
+    int sphere_num;
+    rc_vec3 *position;
+    float *radius;
+    rc_vec3 *color;
+    rc_camera cam;
+} rc_scene;
+
+/* Screen.h:3-9 (24 bytes; surface is a DEVICE pointer) */
+typedef struct rc_screen {
+    void *surface;
+    int width;
+    int height;
+    size_t pitch;
+} rc_screen;
+
+/* Kernel variants.  All produce bit-identical surfaces. */
+enum {
+    RC_VARIANT_AUTO = 0,     /* library picks (the tiled kernel)                          */
+    RC_VARIANT_LITERAL = 1,  /* one pixel per lane, every test evaluated as kernel.cu:52-67 */
+    RC_VARIANT_TILED = 2     /* LDS-staged scene, FMA filter + exact re-test (default)     */
+};
+
+/* What the reference launch lacks (kernel.cu:114-131 has no options). Zero-initialise. */
+typedef struct rc_opts {
+    int y_offset;        /* frame row stored in surface row 0 (row-band rendering)        */
+    int full_height;     /* frame height used in the y angle (kernel.cu:47); 0 = height   */
+    int variant;         /* RC_VARIANT_*                                                   */
+    int reserved0;
+    void *stream;        /* hipStream_t; NULL = the default stream as at kernel.cu:123     */
+    void *rgba8;         /* optional DEVICE R8G8B8A8 surface written with the same frame   */
+    size_t rgba8_pitch;  /* bytes per rgba8 row (>= 4*width)                               */
+    int rgba8_flip;      /* != 0: surface row 0 goes to the LAST rgba8 row (top-down image)*/
+    int reserved1;
+} rc_opts;
+
+/* ---- the hot path ---------------------------------------------------------------------- */
+
+/* Replaces execute_kernel (kernel.cu:114-131, declared by hand at RayTracingKernel.cpp:3-6,
+ * called at RayTracingKernel.cpp:17).  Renders EVERY pixel of the screen (the reference's
+ * floor-divided grid at kernel.cu:121 drops the remainder rows/columns).  Enqueue only. */
+int rc_render(const rc_screen *screen, const rc_scene *scene, const rc_opts *opts);
+
+/* Display step after the path (DXManager.cpp:134,299,328: the float texture drawn 1:1 into
+ * an R8G8B8A8_UNORM target): NaN->0, clamp [0,1], *255 + 0.5, truncate.  Device to device. */
+int rc_to_rgba8(const rc_screen *screen, void *rgba8, size_t rgba8_pitch, int flip, void *stream);
+
+/* ---- host-side helpers that mirror what RayTracingKernel / SceneManager do -------------- */
+
+/* RayTracingKernel.cpp:47-82 findCUDADevice (count + names, no printing) */
+int rc_device_count(int *count);
+int rc_device_name(int device, char *name, size_t name_len);
+int rc_set_device(int device);
+/* number of compute units and max clock of `device` (for roofline reporting) */
+int rc_device_info(int device, int *compute_units, int *clock_khz, size_t *lds_per_block);
+
+/* RayTracingKernel.cpp:93 cudaMallocPitch: pitch = width_bytes rounded up to 256 */
+int rc_malloc_pitch(void **ptr, size_t *pitch, size_t width_bytes, size_t height);
+/* SceneManager.cpp:17,20,23 cudaMalloc */
+int rc_malloc(void **ptr, size_t bytes);
+/* SceneManager.cpp:49-51, RayTracingKernel.cpp:100 cudaFree */
+int rc_free(void *ptr);
+/* RayTracingKernel.cpp:94 cudaMemset */
+int rc_memset(void *ptr, int value, size_t bytes, void *stream);
+/* SceneManager.cpp:18,21,24 cudaMemcpy host->device */
+int rc_upload(void *dst_device, const void *src_host, size_t bytes, void *stream);
+/* replaces the D3D interop copy (RayTracingKernel.cpp:22-27): pitched device->host */
+int rc_download_2d(void *dst_host, size_t dst_pitch, const void *src_device, size_t src_pitch,
+                   size_t width_bytes, size_t height, void *stream);
+/* RayTracingKernel.cpp:18 cudaDeviceSynchronize (stream == NULL: whole device) */
+int rc_sync(void *stream);
+
+/* HIP events on the stream the kernels run on (the reference only has a wall clock,
+ * main.cpp:45-50) */
+int rc_event_create(void **event);
+int rc_event_record(void *event, void *stream);
+int rc_event_elapsed_ms(void *start, void *stop, float *ms); /* waits for `stop` */
+int rc_event_destroy(void *event);
+
+/* Camera.h:43-55,71-91,101-112: position + Euler rotation -> CameraData */
+void rc_camera_data(const rc_vec3 *position, const rc_vec3 *rotation, int width, int height,
+                    rc_camera *out);
+
+/* SceneManager.cpp:14-15,31-46 with a portable float mapping: std::mt19937(seed)
+ * (SceneManager.h:22), u = (r >> 8) * 2^-24, value = lo + u * (hi - lo); per sphere
+ * radius [0.3,1], colour [0,1]^3, x [-10,10], y [-5,5], z [-15,-5].  HOST arrays. */
+void rc_generate_scene(uint32_t seed, int n, rc_vec3 *position, float *radius, rc_vec3 *color);
+
+/* Binary PPM (P6) of a host RGBA8 image whose first row is the top of the picture. */
+int rc_write_ppm(const char *path, const uint8_t *rgba8, size_t pitch, int width, int height);
+
+const char *rc_last_error_string(void);
+/* "rc_hip <version> gfx950" */
+const char *rc_version(void);
+
+#ifdef __cplusplus
+} /* extern "C" */
+#endif
+
+/*
+ * Source-level drop-in for the reference entry point:
+ *
+ *     extern "C" void execute_kernel(Screen screen, Scene scene);     // kernel.cu:114-115
+ *
+ * is exported by librc_hip.so with C linkage and the C++ by-value convention of the
+ * reference types (Scene embeds vec3, whose copy constructor is user-provided at
+ * vec3.h:13-18, so a by-value Scene is passed by invisible reference).  It is declared in
+ * rc_dropin.hpp for C++ callers that do not use the reference's own headers; a caller
+ * that does (RayTracingKernel.cpp:3-6) needs no header from this library at all.
+ */
+#endif /* RC_ABI_H */

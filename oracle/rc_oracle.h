@@ -1,0 +1,115 @@
+/*
+ * rc_oracle.h -- CPU restatement of the reference ray caster (TEST INFRASTRUCTURE ONLY).
+ *
+ * This is the checker, not the product.  Only tests/, __graft_entry__.smoke() and the
+ * cpu_baseline leg of bench.py may load it.  The shipped path (librc_hip.so) never links,
+ * loads or calls anything in this directory.
+ *
+ * Every function restates, operation by operation and in the same association order,
+ * the reference's device code in RayCasting/RayCasting/kernel.cu and vec3.h.  All
+ * arithmetic is IEEE binary32 with NO fused multiply-add (build with -ffp-contract=off),
+ * correctly rounded sqrt and division, and libm's sinf.
+ *
+ * Parity status: pinned by (1) the three known-answer vectors the reference's own device
+ * code produced when it was run on this machine during the survey (FNV-1a hashes + hit
+ * counts, tests/golden/ref_kat.json) and (2) oracle/_ref, which compiles the reference's
+ * own vec3.h / Camera.h untouched and cross-checks the vector algebra and the camera
+ * basis.  kernel.cu itself cannot be built here (needs the CUDA toolkit headers).
+ */
+#ifndef RC_ORACLE_H
+#define RC_ORACLE_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+/* Layout mirrors of the reference argument types (vec3.h:6-10, Camera.h:8-19,
+ * Scene.h:4-13, Screen.h:3-9).  Sizes on LP64: 12 / 56 / 88 / 24 bytes. */
+typedef struct { float x, y, z; } rco_vec3;
+
+typedef struct {
+    float aspect;
+    float fov;
+    rco_vec3 position;
+    rco_vec3 forward;
+    rco_vec3 up;
+    rco_vec3 right;
+} rco_camera;
+
+typedef struct {
+    int sphere_num;
+    rco_vec3 *position;
+    float *radius;
+    rco_vec3 *color;
+    rco_camera cam;
+} rco_scene;
+
+typedef struct {
+    void *surface;
+    int width;
+    int height;
+    size_t pitch;
+} rco_screen;
+
+/* vec3.h:168-176 (norm/length) with vec3.h:89-92 (operator/= is multiply by 1/t). */
+rco_vec3 rco_norm(rco_vec3 v);
+
+/* kernel.cu:44-50 */
+rco_vec3 rco_cast_screen_ray(const rco_camera *c, int x, int y, int width, int height);
+
+/* kernel.cu:52-67 */
+float rco_find_intersection(rco_vec3 pos, float r, rco_vec3 origin, rco_vec3 dir);
+
+/* kernel.cu:21-42 */
+rco_vec3 rco_sphere_color(rco_vec3 position, rco_vec3 color, rco_vec3 point);
+
+/* kernel.cu:69-112 for one (x, y).  `full_height` is the value the reference uses for
+ * screen.height in the y-angle (kernel.cu:47); rows are addressed as y - y_offset inside
+ * `surface`, so a row band can be rendered into a band-sized surface.  With y_offset = 0
+ * and full_height = screen->height this is exactly the reference's draw().
+ * Returns the winning sphere index or -1. */
+int rco_draw_pixel(const rco_screen *screen, const rco_scene *scene, int x, int y,
+                   int y_offset, int full_height);
+
+/* All pixels of rows [row_begin, row_end) of the band described by screen (screen->height
+ * rows starting at frame row y_offset), split over `threads` host threads (>=1). */
+void rco_render_rows(const rco_screen *screen, const rco_scene *scene, int y_offset,
+                     int full_height, int row_begin, int row_end, int threads);
+
+/* Whole frame, reference semantics (y_offset 0, full_height = height). */
+void rco_render(const rco_screen *screen, const rco_scene *scene, int threads);
+
+/* Camera.h:43-55,71-91,101-112: Euler rotation -> CameraData. */
+rco_camera rco_camera_data(rco_vec3 position, rco_vec3 rotation, int width, int height);
+
+/* Deterministic scene in the reference's draw order (SceneManager.cpp:35-45) from
+ * std::mt19937 seeded with `seed` (SceneManager.h:22) and the portable float mapping
+ * u = (r >> 8) * 2^-24, value = lo + u * (hi - lo). */
+void rco_generate_scene(uint32_t seed, int n, rco_vec3 *position, float *radius, rco_vec3 *color);
+
+/* Display step that follows the path in the reference: the float texture is sampled 1:1
+ * into an R8G8B8A8_UNORM target (DXManager.cpp:134,328).  D3D's float->UNORM rule:
+ * NaN -> 0, clamp to [0,1], scale by 255, add 0.5, truncate.
+ * `flip` != 0 writes row 0 of the surface as the LAST output row (surface row 0 is the
+ * bottom of the picture, DXManager.cpp:27). */
+void rco_to_rgba8(const rco_screen *screen, uint8_t *out, size_t out_pitch, int flip);
+
+/* 64-bit FNV-1a over the bytes of the first width*16 bytes of every row. */
+uint64_t rco_fnv1a_surface(const rco_screen *screen);
+
+/* 64-bit FNV-1a taken over the 32-bit WORDS of the same bytes (h ^= word; h *= prime)
+ * from an arbitrary offset basis: the form the recorded reference known-answer hashes use. */
+uint64_t rco_fnv1a64_words(const rco_screen *screen, uint64_t basis);
+
+/* Number of pixels with alpha==1 and any of R,G,B != 0 is NOT the hit mask (a hit may be
+ * black); this packs the true mask from a re-run of the search: bit (y*width + x). */
+void rco_hit_mask(const rco_screen *screen, const rco_scene *scene, int y_offset,
+                  int full_height, uint8_t *mask_bits, int32_t *index_out);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

@@ -1,0 +1,136 @@
+"""C-ABI checks that need no GPU: the library loads, exports every symbol the header declares,
+its structs have the reference layouts, its host-side helpers agree with the oracle, and
+rc_render rejects bad arguments before touching the device."""
+import ctypes as C
+import os
+import re
+import subprocess
+
+import numpy as np
+
+from conftest import ROOT
+from cudaraytracing_amd import abi, configs, host
+
+
+def _declared_symbols():
+    text = open(os.path.join(ROOT, "include", "rc_abi.h")).read()
+    text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
+    names = set(re.findall(r"\b(rc_[a-z0-9_]+)\s*\(", text))
+    return names
+
+
+def test_library_exports_every_declared_symbol(rclib):
+    declared = _declared_symbols()
+    assert len(declared) >= 20
+    assert declared <= set(abi.SYMBOLS), declared - set(abi.SYMBOLS)
+    out = subprocess.run(["nm", "-D", "--defined-only", abi.LIB_PATH], capture_output=True, text=True, check=True).stdout
+    exported = {line.split()[-1] for line in out.splitlines() if line.strip()}
+    for name in declared | {"execute_kernel"}:
+        assert name in exported, f"{name} is declared but not exported"
+
+
+def test_library_does_not_link_the_oracle():
+    out = subprocess.run(["ldd", abi.LIB_PATH], capture_output=True, text=True).stdout
+    assert "oracle" not in out
+    syms = subprocess.run(["nm", "-D", abi.LIB_PATH], capture_output=True, text=True).stdout
+    assert "rco_" not in syms
+
+
+def test_struct_layouts():
+    assert C.sizeof(abi.RcVec3) == 12
+    assert C.sizeof(abi.RcCamera) == 56
+    assert C.sizeof(abi.RcScene) == 88 and abi.RcScene.cam.offset == 32
+    assert C.sizeof(abi.RcScreen) == 24 and abi.RcScreen.pitch.offset == 16
+
+
+def test_version_and_error_string(rclib):
+    assert rclib.rc_version().startswith(b"rc_hip")
+    assert isinstance(rclib.rc_last_error_string(), bytes)
+
+
+def test_generate_scene_matches_oracle(oracle):
+    for n, seed in [(0, 0), (1, 0), (8, 0), (1024, 0), (4096, 7)]:
+        a = host.generate_scene(n, seed)
+        b = oracle.generate_scene(n, seed)
+        for x, y in zip(a, b):
+            assert np.array_equal(x.view(np.uint32), y.view(np.uint32))
+    pos, rad, col = host.generate_scene(4096, 0)
+    assert rad.min() >= 0.3 and rad.max() <= 1.0
+    assert np.all(np.abs(pos[:, 0]) <= 10) and np.all(np.abs(pos[:, 1]) <= 5)
+    assert pos[:, 2].min() >= -15 and pos[:, 2].max() <= -5
+    assert col.min() >= 0 and col.max() <= 1
+
+
+def test_camera_data_matches_oracle(oracle):
+    rng = np.random.default_rng(0)
+    cams = [((0, 0, 20), (0, 0, 0), 640, 480)]
+    for _ in range(500):
+        cams.append((tuple(rng.uniform(-30, 30, 3)), (rng.uniform(-3, 3), rng.uniform(-3, 3), 0.0),
+                     int(rng.integers(1, 8000)), int(rng.integers(1, 5000))))
+    for f in (0, 37, 150, 299):
+        p, r = configs.sequence_camera(f)
+        cams.append((p, r, 3840, 2160))
+    for p, r, w, h in cams:
+        cam = host.Camera(w, h)
+        cam.position, cam.rotation = p, r
+        got = cam.get_data()
+        want = oracle.camera_data(p, r, w, h)
+        assert bytes(got) == bytes(want)
+
+
+def test_render_rejects_bad_arguments(rclib):
+    scene = abi.RcScene()
+    fake = 0x1000
+    cases = [
+        (abi.RcScreen(None, 64, 64, 1024), "null surface"),
+        (abi.RcScreen(fake, 0, 64, 1024), "zero width"),
+        (abi.RcScreen(fake, 64, -1, 1024), "negative height"),
+        (abi.RcScreen(fake, 64, 64, 1000), "pitch too small"),
+        (abi.RcScreen(fake, 64, 64, 1032), "pitch not multiple of 16"),
+        (abi.RcScreen(fake + 4, 64, 64, 1024), "misaligned surface"),
+    ]
+    for screen, what in cases:
+        assert rclib.rc_render(C.byref(screen), C.byref(scene), None) == abi.RC_EINVAL, what
+        assert rclib.rc_last_error_string() != b""
+    ok = abi.RcScreen(fake, 64, 64, 1024)
+    assert rclib.rc_render(None, C.byref(scene), None) == abi.RC_EINVAL
+    assert rclib.rc_render(C.byref(ok), None, None) == abi.RC_EINVAL
+    bad = abi.RcScene()
+    bad.sphere_num = -1
+    assert rclib.rc_render(C.byref(ok), C.byref(bad), None) == abi.RC_EINVAL
+    bad.sphere_num = 3                       # arrays are null
+    assert rclib.rc_render(C.byref(ok), C.byref(bad), None) == abi.RC_EINVAL
+    for o in (abi.RcOpts(y_offset=-1), abi.RcOpts(y_offset=10, full_height=64), abi.RcOpts(variant=99),
+              abi.RcOpts(rgba8=fake, rgba8_pitch=8)):
+        assert rclib.rc_render(C.byref(ok), C.byref(scene), C.byref(o)) == abi.RC_EINVAL
+
+
+def test_write_ppm(rclib, tmp_path):
+    img = np.arange(5 * 3 * 4, dtype=np.uint8).reshape(3, 5, 4)
+    path = tmp_path / "t.ppm"
+    assert rclib.rc_write_ppm(str(path).encode(), img.ctypes.data_as(C.c_void_p), 20, 5, 3) == 0
+    data = path.read_bytes()
+    assert data.startswith(b"P6\n5 3\n255\n")
+    body = np.frombuffer(data[len(b"P6\n5 3\n255\n"):], np.uint8).reshape(3, 5, 3)
+    assert np.array_equal(body, img[..., :3])
+    assert rclib.rc_write_ppm(None, None, 0, 0, 0) == abi.RC_EINVAL
+
+
+def test_band_rows_partition():
+    for h in (1, 7, 540, 1080, 2160, 4320, 4321):
+        for world in (1, 2, 3, 4, 8):
+            spans = [configs.band_rows(h, world, r) for r in range(world)]
+            assert spans[0][0] == 0 and spans[-1][1] == h
+            for a, b in zip(spans, spans[1:]):
+                assert a[1] == b[0]
+            sizes = [e - b for b, e in spans]
+            assert max(sizes) - min(sizes) <= 1
+
+
+def test_sequence_camera_is_float_exact_and_periodic():
+    p0, r0 = configs.sequence_camera(0)
+    assert p0 == (0.0, 0.0, 20.0) and r0 == (0.0, 0.0, 0.0)
+    for f in range(0, 300, 17):
+        p, r = configs.sequence_camera(f)
+        assert all(float(np.float32(v)) == v for v in p + r)
+        assert r[2] == 0.0 and p[2] == 20.0

@@ -1,0 +1,108 @@
+"""The oracle against everything that pins it (CPU only).
+
+1. ref_kat.json: outputs of the reference's own device code (recorded when it was run on
+   this machine during the survey): full-surface hash + hit count at 8 / 64 / 1024 spheres.
+2. oracle/_ref/ref_algebra: the reference's vec3.h / Camera.h compiled untouched, compared
+   bit for bit with the oracle's vector algebra, camera basis and ray generation.
+3. golden.json: the oracle's own committed outputs (regression pin of the fixtures the GPU
+   tests rely on), small frames re-rendered here; sampled pixels of every frame re-checked.
+"""
+import os
+import subprocess
+
+import numpy as np
+import pytest
+
+from conftest import ROOT
+
+
+@pytest.mark.parametrize("k", [0, 1, 2])
+def test_reference_known_answers(oracle, ref_kat, kat_scene, k):
+    v = ref_kat["vectors"][k]
+    pos, rad, col = (a[: v["n"]] for a in kat_scene)
+    w, h = ref_kat["width"], ref_kat["height"]
+    cam = oracle.camera_data(ref_kat["camera_position"], ref_kat["camera_rotation"], w, h)
+    surf = oracle.render(pos, rad, col, cam, w, h)
+    assert f"{oracle.fnv_words(surf, ref_kat['fnv_offset_basis']):016x}" == v["fnv"]
+    idx = oracle.hit_index(pos, rad, col, cam, w, h)
+    assert int((idx >= 0).sum()) == v["hits"]
+    assert np.all(surf[..., 3] == 1.0)
+
+
+def test_kat_camera_matches_survey(oracle):
+    cam = oracle.camera_data((0, 0, 20), (0, 0, 0), 640, 480)
+    assert (cam.forward.x, cam.forward.y, cam.forward.z) == (0.0, 0.0, -1.0)
+    assert np.signbit(np.float32(cam.forward.x))            # -0, as the reference prints it
+    assert (cam.up.x, cam.up.y, cam.up.z) == (0.0, 1.0, 0.0)
+    assert (cam.right.x, cam.right.y, cam.right.z) == (1.0, 0.0, 0.0)
+    assert np.float32(cam.fov) == np.float32(0.785398185)
+    assert np.float32(cam.aspect) == np.float32(640 / 480)
+
+
+def test_reference_headers_cross_check():
+    exe = os.path.join(ROOT, "oracle", "_ref", "ref_algebra")
+    if not os.path.exists(exe):
+        pytest.skip("oracle/_ref/ref_algebra not built (reference sources absent on this machine)")
+    r = subprocess.run([exe], capture_output=True, text=True, timeout=120)
+    assert r.returncode == 0, r.stdout + r.stderr
+    assert " 0 mismatches" in r.stdout
+
+
+def _render_frame(oracle, fx, rows=None):
+    pos, rad, col = oracle.generate_scene(fx["n"], fx["seed"])
+    cam = oracle.camera_data(fx["position"], fx["rotation"], fx["width"], fx["height"])
+    return pos, rad, col, cam
+
+
+@pytest.mark.parametrize("name", ["c1_640x480_n8", "c2_1920x1080_n64", "ref_1280x768_n512"])
+def test_golden_small_frames(oracle, golden, name):
+    fx = golden[name]
+    pos, rad, col, cam = _render_frame(oracle, fx)
+    surf = oracle.render(pos, rad, col, cam, fx["width"], fx["height"])
+    assert f"{oracle.fnv_words(surf):016x}" == fx["fnv"]
+    assert int(surf[..., :3].any(axis=2).sum()) == fx["lit_pixels"]
+    bits = surf.view(np.uint32)
+    for s in fx["samples"]:
+        assert bits[s[1], s[0]].tolist() == s[2:6]
+
+
+def test_golden_samples_all_frames(oracle, golden):
+    """Every committed frame, full-size ones included: re-trace only the sampled pixels."""
+    import ctypes as C
+    lib = oracle.load()
+    for fx in golden.values():
+        pos, rad, col, cam = _render_frame(oracle, fx)
+        scene, keep = oracle.make_scene(pos, rad, col, cam)
+        w, h = fx["width"], fx["height"]
+        row = np.zeros((1, w * 4), np.float32)
+        for s in fx["samples"]:
+            x, y = s[0], s[1]
+            scr = oracle.Screen(row.ctypes.data, w, 1, w * 16)
+            lib.rco_draw_pixel.argtypes = [C.POINTER(oracle.Screen), C.POINTER(oracle.Scene), C.c_int, C.c_int, C.c_int, C.c_int]
+            lib.rco_draw_pixel(C.byref(scr), C.byref(scene), x, y, y, h)
+            assert row.view(np.uint32)[0, 4 * x: 4 * x + 4].tolist() == s[2:6], (fx["name"], x, y)
+        got = np.frombuffer(C.string_at(C.addressof(cam), C.sizeof(cam)), np.uint32).tolist()
+        assert got == fx["camera_bits"]
+
+
+def test_row_band_equals_full_frame(oracle):
+    pos, rad, col = oracle.generate_scene(64, 0)
+    w, h = 320, 200
+    cam = oracle.camera_data((0, 0, 20), (0.1, -0.2, 0), w, h)
+    full = oracle.render(pos, rad, col, cam, w, h)
+    band = oracle.render(pos, rad, col, cam, w, 50, y_offset=100, full_height=h)
+    assert np.array_equal(full[100:150].view(np.uint32), band.view(np.uint32))
+
+
+def test_rgba8_rule(oracle):
+    surf = np.zeros((2, 3, 4), np.float32)
+    surf[0, 0] = [0.0, 1.0, 2.0, -1.0]
+    surf[0, 1] = [np.nan, 0.5, 0.999, 1.0]
+    surf[0, 2] = [0.25, 0.75, 1e-9, np.inf]
+    surf[1, 0] = [0.5 / 255, 1.5 / 255, 254.5 / 255, 1.0]
+    out = oracle.to_rgba8(surf, flip=False)
+    assert out[0, 0].tolist() == [0, 255, 255, 0]
+    assert out[0, 1].tolist() == [0, 128, 255, 255]
+    assert out[0, 2].tolist() == [64, 191, 0, 255]
+    flipped = oracle.to_rgba8(surf, flip=True)
+    assert np.array_equal(flipped[::-1], out)

@@ -1,0 +1,229 @@
+"""GPU parity tests proper: the HIP path, called through the C ABI, against the CPU oracle.
+
+Bar: bit-exact float surfaces (hence bit-exact hit masks and winner indices); bit-exact RGBA8.
+Small frames are compared with the oracle run here on the same inputs; full-size frames with
+the committed golden hashes (tests/golden/golden.json) and with size-independent properties
+(tiled kernel == literal kernel, row bands == full frame).
+"""
+import ctypes as C
+import os
+import subprocess
+
+import numpy as np
+import pytest
+
+from conftest import ROOT
+from cudaraytracing_amd import abi, configs
+from gpu_util import GpuScene, assert_same_bits, gpu_render, pixels
+
+pytestmark = pytest.mark.gpu
+
+VARIANTS = [abi.VARIANT_TILED, abi.VARIANT_TILED2, abi.VARIANT_LITERAL]
+
+
+def _frame(oracle, name):
+    c = configs.CONFIGS[name]
+    pos, rad, col = oracle.generate_scene(c["n"], c["seed"])
+    cam = oracle.camera_data(c["position"], c["rotation"], c["width"], c["height"])
+    return c, pos, rad, col, cam
+
+
+@pytest.mark.parametrize("variant", VARIANTS)
+@pytest.mark.parametrize("name", ["c1_640x480_n8", "c2_1920x1080_n64", "ref_1280x768_n512"])
+def test_small_frames_bit_exact(oracle, golden, name, variant):
+    c, pos, rad, col, cam = _frame(oracle, name)
+    w, h = c["width"], c["height"]
+    want = oracle.render(pos, rad, col, cam, w, h)
+    got = pixels(gpu_render(pos, rad, col, cam, w, h, variant=variant), w)
+    assert_same_bits(got, want, name)
+    assert f"{oracle.fnv_words(got):016x}" == golden[name]["fnv"]
+
+
+@pytest.mark.parametrize("variant", VARIANTS)
+def test_reference_known_answers_on_gpu(oracle, ref_kat, kat_scene, variant):
+    """The reference's own recorded outputs, reproduced by the HIP path."""
+    w, h = ref_kat["width"], ref_kat["height"]
+    cam = oracle.camera_data(ref_kat["camera_position"], ref_kat["camera_rotation"], w, h)
+    for v in ref_kat["vectors"]:
+        pos, rad, col = (a[: v["n"]] for a in kat_scene)
+        got = pixels(gpu_render(pos, rad, col, cam, w, h, variant=variant), w)
+        assert f"{oracle.fnv_words(got, ref_kat['fnv_offset_basis']):016x}" == v["fnv"]
+
+
+@pytest.mark.parametrize("variant", VARIANTS)
+@pytest.mark.parametrize("w,h,n", [(333, 77, 5), (1, 1, 3), (65, 17, 1), (640, 480, 0), (31, 9, 7),
+                                    (200, 120, 2049), (96, 64, 4100)])
+def test_ragged_sizes_and_counts(oracle, w, h, n, variant):
+    pos, rad, col = oracle.generate_scene(n, 3)
+    cam = oracle.camera_data((0.5, -0.25, 21.0), (0.05, 0.1, 0.0), w, h)
+    want = oracle.render(pos, rad, col, cam, w, h)
+    got = pixels(gpu_render(pos, rad, col, cam, w, h, variant=variant), w)
+    assert_same_bits(got, want, f"{w}x{h} n={n}")
+
+
+@pytest.mark.parametrize("variant", VARIANTS)
+def test_rotated_and_inside_cameras(oracle, variant):
+    pos, rad, col = oracle.generate_scene(300, 9)
+    w, h = 480, 270
+    cams = [((0, 0, 20), (0.3, -0.7, 0)), ((3, 1, -2), (-0.4, 2.9, 0)), ((0, 0, -10), (0, 3.14159, 0)),
+            (tuple(pos[17]), (0, 0, 0)),                               # camera at a sphere centre
+            (tuple(pos[5] + np.float32([0, 0, 0.9]) * rad[5]), (0.2, 0.1, 0)),   # inside a sphere
+            (tuple(pos[8] + np.float32([0, 0, 1.0]) * rad[8]), (0, 0, 0)),       # on a surface
+            (tuple(pos[8] + np.float32([0, 0, 1.0 + 2e-6]) * rad[8]), (0, 0, 0))]  # grazing shell
+    for p, r in cams:
+        cam = oracle.camera_data(p, r, w, h)
+        want = oracle.render(pos, rad, col, cam, w, h)
+        got = pixels(gpu_render(pos, rad, col, cam, w, h, variant=variant), w)
+        assert_same_bits(got, want, f"camera {p} {r}")
+
+
+@pytest.mark.parametrize("variant", VARIANTS)
+def test_ties_and_degenerate_spheres(oracle, variant):
+    """Equal distances (duplicate spheres: lowest index wins, kernel.cu:91), zero/negative/
+    NaN/Inf radii and positions, hits beyond the 10000 cut-off (kernel.cu:85)."""
+    pos, rad, col = oracle.generate_scene(40, 5)
+    pos[10] = pos[3]; rad[10] = rad[3]          # duplicate, different colour
+    pos[11] = pos[3]; rad[11] = rad[3]
+    rad[12] = 0.0
+    rad[13] = -0.7                              # r*r is what matters
+    rad[14] = np.nan
+    rad[15] = np.inf
+    pos[16] = [np.nan, 0, -10]
+    pos[17] = [np.inf, 0, -10]
+    pos[18] = [0, 0, -20000]; rad[18] = 5000    # nearest root > 10000: ignored
+    pos[19] = [0, 0, -9990]; rad[19] = 30
+    pos[20] = [1e30, 0, 0]; rad[20] = 1e30
+    pos[21] = [0, 0, 1e20]; rad[21] = 1e20
+    pos[22] = [1e-30, 1e-30, 20]; rad[22] = 1e-20   # tiny sphere at the camera
+    w, h = 400, 300
+    cam = oracle.camera_data((0, 0, 20), (0, 0, 0), w, h)
+    want = oracle.render(pos, rad, col, cam, w, h)
+    got = pixels(gpu_render(pos, rad, col, cam, w, h, variant=variant), w)
+    assert_same_bits(got, want, "degenerate spheres")
+
+
+@pytest.mark.parametrize("variant", VARIANTS)
+def test_degenerate_camera_vectors(oracle, variant):
+    """Non-unit / zero / NaN camera basis (CameraData is caller-supplied, Scene.h:12)."""
+    pos, rad, col = oracle.generate_scene(50, 2)
+    w, h = 160, 90
+    base = oracle.camera_data((0, 0, 20), (0, 0, 0), w, h)
+    for tweak in ("zero_forward", "huge", "nan_up", "tiny"):
+        cam = oracle.Camera.from_buffer_copy(bytes(base))
+        if tweak == "zero_forward":
+            cam.forward.x = cam.forward.y = cam.forward.z = 0.0
+            cam.right.x = 0.0; cam.up.y = 0.0
+        elif tweak == "huge":
+            cam.forward.z = -1e30
+        elif tweak == "nan_up":
+            cam.up.y = float("nan")
+        elif tweak == "tiny":
+            cam.forward.z = -1e-25; cam.right.x = 1e-25; cam.up.y = 1e-25
+        want = oracle.render(pos, rad, col, cam, w, h)
+        got = pixels(gpu_render(pos, rad, col, cam, w, h, variant=variant), w)
+        assert_same_bits(got, want, tweak)
+
+
+def test_pitch_padding_untouched(oracle):
+    pos, rad, col = oracle.generate_scene(16, 1)
+    w, h = 100, 40
+    cam = oracle.camera_data((0, 0, 20), (0, 0, 0), w, h)
+    pitch = 2048
+    raw = gpu_render(pos, rad, col, cam, w, h, pitch=pitch, fill=1)
+    want = oracle.render(pos, rad, col, cam, w, h)
+    assert_same_bits(pixels(raw, w), want, "pitched surface")
+    pad = raw[:, w * 4:].view(np.uint32)
+    assert np.all(pad == 0x01010101)            # the memset pattern of RayTracingKernel.cpp:94
+
+
+@pytest.mark.parametrize("variant", [abi.VARIANT_TILED, abi.VARIANT_LITERAL])
+def test_row_bands_equal_full_frame(oracle, variant):
+    c, pos, rad, col, cam = _frame(oracle, "c2_1920x1080_n64")
+    w, h = c["width"], c["height"]
+    scene = GpuScene(pos, rad, col)
+    full = pixels(gpu_render(pos, rad, col, cam, w, h, variant=variant, scene=scene), w)
+    for world in (2, 8, 7):
+        parts = []
+        for rank in range(world):
+            b, e = configs.band_rows(h, world, rank)
+            parts.append(pixels(gpu_render(pos, rad, col, cam, w, e - b, variant=variant, y_offset=b,
+                                           full_height=h, scene=scene), w))
+        assert_same_bits(np.concatenate(parts, axis=0), full, f"{world} bands")
+    scene.free()
+
+
+def test_rgba8_fused_and_standalone(oracle):
+    c, pos, rad, col, cam = _frame(oracle, "c1_640x480_n8")
+    w, h = c["width"], c["height"]
+    for flip in (False, True):
+        raw, fused = gpu_render(pos, rad, col, cam, w, h, want_rgba8=True, flip=flip)
+        want8 = oracle.to_rgba8(pixels(raw, w), flip=flip)
+        assert np.array_equal(fused, want8)
+    # standalone conversion kernel on a surface with NaN / out-of-range values
+    lib = abi.load()
+    from cudaraytracing_amd.host import DeviceBuffer
+    rng = np.random.default_rng(0)
+    surf = rng.uniform(-0.5, 1.5, (37, 53, 4)).astype(np.float32)
+    surf[3, 4, 0] = np.nan; surf[5, 6, 1] = np.inf; surf[7, 8, 2] = -np.inf
+    d_in, d_out = DeviceBuffer(surf.nbytes), DeviceBuffer(37 * 53 * 4)
+    d_in.upload(surf)
+    screen = abi.RcScreen(d_in.ptr.value, 53, 37, 53 * 16)
+    abi.check(lib.rc_to_rgba8(C.byref(screen), d_out.ptr, 53 * 4, 1, None))
+    abi.check(lib.rc_sync(None))
+    got = np.empty((37, 53, 4), np.uint8)
+    abi.check(lib.rc_download_2d(got.ctypes.data_as(C.c_void_p), 53 * 4, d_out.ptr, 53 * 4, 53 * 4, 37, None))
+    assert np.array_equal(got, oracle.to_rgba8(surf, flip=True))
+    d_in.free(); d_out.free()
+
+
+@pytest.mark.parametrize("name", ["c3_3840x2160_n1024", "c4_7680x4320_n4096",
+                                  "c5_seq_f0", "c5_seq_f37", "c5_seq_f150", "c5_seq_f299"])
+def test_full_size_golden_hashes(oracle, golden, name):
+    """BASELINE-size frames against the oracle's committed hashes; tiled == literal as well."""
+    if name not in golden:
+        pytest.fail(f"{name} missing from tests/golden/golden.json (run make_golden.py --full)")
+    fx = golden[name]
+    w, h = fx["width"], fx["height"]
+    pos, rad, col = oracle.generate_scene(fx["n"], fx["seed"])
+    cam = oracle.camera_data(fx["position"], fx["rotation"], w, h)
+    got_cam = np.frombuffer(C.string_at(C.addressof(cam), C.sizeof(cam)), np.uint32).tolist()
+    assert got_cam == fx["camera_bits"]
+    scene = GpuScene(pos, rad, col)
+    raw, rgba8 = gpu_render(pos, rad, col, cam, w, h, variant=abi.VARIANT_TILED, want_rgba8=True, flip=True, scene=scene)
+    got = pixels(raw, w)
+    assert f"{oracle.fnv_words(got):016x}" == fx["fnv"]
+    assert int(got[..., :3].any(axis=2).sum()) == fx["lit_pixels"]
+    bits = got.view(np.uint32)
+    for s in fx["samples"]:
+        assert bits[s[1], s[0]].tolist() == s[2:6]
+    import hashlib  # noqa: F401  (rgba8 hash uses the oracle's word hash over a flat view)
+    flat = np.ascontiguousarray(rgba8).view(np.uint32).reshape(1, -1)
+    scr = oracle.Screen(flat.ctypes.data, flat.shape[1] // 4, 1, flat.shape[1] * 4)
+    assert f"{int(oracle.load().rco_fnv1a64_words(C.byref(scr), oracle.FNV_BASIS)):016x}" == fx["rgba8_flip_fnv"]
+    if name.startswith("c3") or name.startswith("c4"):
+        lit = pixels(gpu_render(pos, rad, col, cam, w, h, variant=abi.VARIANT_LITERAL, scene=scene), w)
+        assert_same_bits(lit, got, "literal vs tiled")
+    scene.free()
+
+
+def test_dropin_execute_kernel_from_reference_call_site(oracle, tmp_path):
+    """oracle/_ref/dropin_caller was compiled against the reference's own Screen.h/Scene.h/
+    Camera.h and calls execute_kernel(Screen, Scene) by value, as RayTracingKernel.cpp:17."""
+    exe = os.path.join(ROOT, "oracle", "_ref", "dropin_caller")
+    if not os.path.exists(exe):
+        pytest.fail("oracle/_ref/dropin_caller missing: build it in the container with `make -C oracle`")
+    w, h, n, seed = 1280, 768, 512, 0      # the reference's own window and sphere count
+    out = tmp_path / "dropin.raw"
+    r = subprocess.run([exe, str(w), str(h), str(n), str(seed), str(out)], capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, r.stdout + r.stderr
+    got = np.fromfile(out, np.float32).reshape(h, w, 4)
+    pos, rad, col = oracle.generate_scene(n, seed)
+    cam = oracle.camera_data((0, 0, 20), (0, 0, 0), w, h)
+    assert_same_bits(got, oracle.render(pos, rad, col, cam, w, h), "drop-in execute_kernel")
+
+
+def test_argument_validation_on_device(rclib):
+    screen = abi.RcScreen(None, 64, 64, 1024)
+    scene = abi.RcScene()
+    assert rclib.rc_render(C.byref(screen), C.byref(scene), None) == abi.RC_EINVAL
+    assert b"surface" in rclib.rc_last_error_string()

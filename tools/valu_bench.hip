@@ -1,0 +1,92 @@
+// valu_bench.hip -- measures VALU issue rates on gfx950 that the tiled kernel's design rests on:
+// plain v_fma_f32 vs packed v_pk_fma_f32 / v_pk_mul_f32 vs v_max3_f32, at 1..8 waves per SIMD.
+// Build: hipcc --offload-arch=gfx950 -O3 tools/valu_bench.hip -o build/valu_bench
+#include <hip/hip_runtime.h>
+#include <stdio.h>
+#include <stdlib.h>
+
+#define REP16(x) x x x x x x x x x x x x x x x x
+
+template <int KIND>
+__global__ __launch_bounds__(256) void k(float *out, int iters, float seed)
+{
+    float a0 = seed + threadIdx.x, a1 = a0 + 1, a2 = a0 + 2, a3 = a0 + 3, a4 = a0 + 4, a5 = a0 + 5, a6 = a0 + 6, a7 = a0 + 7;
+    float b = seed * 0.5f, c = seed * 0.25f;
+    typedef float f2 __attribute__((ext_vector_type(2)));
+    f2 p0 = {a0, a1}, p1 = {a2, a3}, p2 = {a4, a5}, p3 = {a6, a7}, pb = {b, b}, pc = {c, c};
+    for (int i = 0; i < iters; i++) {
+        if (KIND == 0) {   // 8 independent v_fma_f32 x16
+            REP16(asm volatile("v_fma_f32 %0, %0, %8, %9\n v_fma_f32 %1, %1, %8, %9\n v_fma_f32 %2, %2, %8, %9\n v_fma_f32 %3, %3, %8, %9\n"
+                         "v_fma_f32 %4, %4, %8, %9\n v_fma_f32 %5, %5, %8, %9\n v_fma_f32 %6, %6, %8, %9\n v_fma_f32 %7, %7, %8, %9\n"
+                         : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3), "+v"(a4), "+v"(a5), "+v"(a6), "+v"(a7) : "v"(b), "v"(c));)
+        } else if (KIND == 1) {   // 4 independent v_pk_fma_f32 x16 (8 FMAs per line, as KIND 0)
+            REP16(asm volatile("v_pk_fma_f32 %0, %0, %4, %5\n v_pk_fma_f32 %1, %1, %4, %5\n v_pk_fma_f32 %2, %2, %4, %5\n v_pk_fma_f32 %3, %3, %4, %5\n"
+                         : "+v"(p0), "+v"(p1), "+v"(p2), "+v"(p3) : "v"(pb), "v"(pc));)
+        } else if (KIND == 2) {   // v_pk_mul_f32
+            REP16(asm volatile("v_pk_mul_f32 %0, %0, %4\n v_pk_mul_f32 %1, %1, %4\n v_pk_mul_f32 %2, %2, %4\n v_pk_mul_f32 %3, %3, %4\n"
+                         : "+v"(p0), "+v"(p1), "+v"(p2), "+v"(p3) : "v"(pb));)
+        } else if (KIND == 3) {   // 8 x v_max3_f32 with abs modifiers
+            REP16(asm volatile("v_max3_f32 %0, %0, |%8|, |%9|\n v_max3_f32 %1, %1, |%8|, |%9|\n v_max3_f32 %2, %2, |%8|, |%9|\n v_max3_f32 %3, %3, |%8|, |%9|\n"
+                         "v_max3_f32 %4, %4, |%8|, |%9|\n v_max3_f32 %5, %5, |%8|, |%9|\n v_max3_f32 %6, %6, |%8|, |%9|\n v_max3_f32 %7, %7, |%8|, |%9|\n"
+                         : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3), "+v"(a4), "+v"(a5), "+v"(a6), "+v"(a7) : "v"(b), "v"(c));)
+        } else if (KIND == 4) {   // 8 x v_mul_f32
+            REP16(asm volatile("v_mul_f32 %0, %0, %8\n v_mul_f32 %1, %1, %8\n v_mul_f32 %2, %2, %8\n v_mul_f32 %3, %3, %8\n"
+                         "v_mul_f32 %4, %4, %8\n v_mul_f32 %5, %5, %8\n v_mul_f32 %6, %6, %8\n v_mul_f32 %7, %7, %8\n"
+                         : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3), "+v"(a4), "+v"(a5), "+v"(a6), "+v"(a7) : "v"(b));)
+        } else if (KIND == 5) {   // v_fma_f32 with an SGPR operand
+            REP16(asm volatile("v_fma_f32 %0, %0, %8, %9\n v_fma_f32 %1, %1, %8, %9\n v_fma_f32 %2, %2, %8, %9\n v_fma_f32 %3, %3, %8, %9\n"
+                         "v_fma_f32 %4, %4, %8, %9\n v_fma_f32 %5, %5, %8, %9\n v_fma_f32 %6, %6, %8, %9\n v_fma_f32 %7, %7, %8, %9\n"
+                         : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3), "+v"(a4), "+v"(a5), "+v"(a6), "+v"(a7) : "s"(seed), "v"(c));)
+        } else if (KIND == 6) {   // v_pk_fma_f32 with op_sel broadcast (as the compiler emits)
+            REP16(asm volatile("v_pk_fma_f32 %0, %4, %0, %5 op_sel_hi:[0,1,1]\n v_pk_fma_f32 %1, %4, %1, %5 op_sel_hi:[0,1,1]\n v_pk_fma_f32 %2, %4, %2, %5 op_sel_hi:[0,1,1]\n v_pk_fma_f32 %3, %4, %3, %5 op_sel_hi:[0,1,1]\n"
+                         : "+v"(p0), "+v"(p1), "+v"(p2), "+v"(p3) : "v"(pb), "v"(pc));)
+        }
+    }
+    float r = a0 + a1 + a2 + a3 + a4 + a5 + a6 + a7 + p0.x + p0.y + p1.x + p1.y + p2.x + p2.y + p3.x + p3.y;
+    if (r == 12345.678f) out[threadIdx.x] = r;
+}
+
+template <int KIND>
+static void run(const char *name, double flop_per_line, int lines_vinst)
+{
+    float *out;
+    hipMalloc(&out, 4096);
+    hipEvent_t e0, e1;
+    hipEventCreate(&e0);
+    hipEventCreate(&e1);
+    int cus = 256;
+    hipDeviceProp_t p;
+    hipGetDeviceProperties(&p, 0);
+    cus = p.multiProcessorCount;
+    for (int wps = 1; wps <= 8; wps *= 2) {
+        int blocks = cus * wps;   // 256 threads = 1 wave per SIMD per block
+        int iters = 4000;
+        hipLaunchKernelGGL(k<KIND>, dim3(blocks), dim3(256), 0, 0, out, 100, 1.0f);
+        hipDeviceSynchronize();
+        hipEventRecord(e0);
+        hipLaunchKernelGGL(k<KIND>, dim3(blocks), dim3(256), 0, 0, out, iters, 1.0f);
+        hipEventRecord(e1);
+        hipEventSynchronize(e1);
+        float ms;
+        hipEventElapsedTime(&ms, e0, e1);
+        double vinst_per_wave = (double)iters * 16 * lines_vinst;
+        double clk = p.clockRate * 1e3;
+        double cyc_per_inst = ms * 1e-3 * clk / (vinst_per_wave * wps);
+        double tflops = flop_per_line * 16.0 * iters * 64.0 * 4.0 * wps * cus / (ms * 1e-3) / 1e12;
+        printf("%-28s waves/SIMD=%d  %.3f ms  %.2f cyc/inst/SIMD (at %.0f MHz)  %.1f TFLOP/s\n", name, wps, ms,
+               cyc_per_inst, clk / 1e6, tflops);
+    }
+    hipFree(out);
+}
+
+int main()
+{
+    run<0>("v_fma_f32", 16, 8);
+    run<1>("v_pk_fma_f32", 16, 4);
+    run<6>("v_pk_fma_f32 op_sel", 16, 4);
+    run<2>("v_pk_mul_f32", 8, 4);
+    run<3>("v_max3_f32 |abs|", 16, 8);
+    run<4>("v_mul_f32", 8, 8);
+    run<5>("v_fma_f32 sgpr-src", 16, 8);
+    return 0;
+}
