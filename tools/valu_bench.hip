@@ -7,6 +7,25 @@
 
 #define REP16(x) x x x x x x x x x x x x x x x x
 
+
+#define KIND8(NUM, INSTR) else if (KIND == NUM) { \
+            REP16(asm volatile(INSTR(0) INSTR(1) INSTR(2) INSTR(3) INSTR(4) INSTR(5) INSTR(6) INSTR(7) \
+                         : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3), "+v"(a4), "+v"(a5), "+v"(a6), "+v"(a7) : "v"(b), "v"(c));) }
+#define I_OR3(i) "v_or3_b32 %" #i ", %" #i ", %8, %9\n"
+#define I_ANDOR(i) "v_and_or_b32 %" #i ", %" #i ", %8, %9\n"
+#define I_MAX2(i) "v_max_f32 %" #i ", %" #i ", %8\n"
+#define I_MAX2ABS(i) "v_max_f32_e64 %" #i ", %" #i ", |%8|\n"
+#define I_PKMAXI16(i) "v_pk_max_i16 %" #i ", %" #i ", %8\n"
+#define I_MAX3I(i) "v_max3_i32 %" #i ", %" #i ", %8, %9\n"
+#define I_AND(i) "v_and_b32 %" #i ", %" #i ", %8\n"
+#define I_PERM(i) "v_perm_b32 %" #i ", %" #i ", %8, %9\n"
+#define I_FMAMIX(i) "v_fma_f32 %" #i ", %8, %9, %" #i "\n"
+#define I_MED3(i) "v_med3_f32 %" #i ", %" #i ", %8, %9\n"
+#define I_MIN3(i) "v_min3_f32 %" #i ", %" #i ", %8, %9\n"
+#define I_ADD3(i) "v_add3_u32 %" #i ", %" #i ", %8, %9\n"
+#define I_LSHLOR(i) "v_lshl_or_b32 %" #i ", %" #i ", %8, %9\n"
+#define I_CMP(i) "v_cmp_ge_f32 vcc, %" #i ", %8\n"
+
 template <int KIND>
 __global__ __launch_bounds__(256) void k(float *out, int iters, float seed)
 {
@@ -41,6 +60,11 @@ __global__ __launch_bounds__(256) void k(float *out, int iters, float seed)
             REP16(asm volatile("v_pk_fma_f32 %0, %4, %0, %5 op_sel_hi:[0,1,1]\n v_pk_fma_f32 %1, %4, %1, %5 op_sel_hi:[0,1,1]\n v_pk_fma_f32 %2, %4, %2, %5 op_sel_hi:[0,1,1]\n v_pk_fma_f32 %3, %4, %3, %5 op_sel_hi:[0,1,1]\n"
                          : "+v"(p0), "+v"(p1), "+v"(p2), "+v"(p3) : "v"(pb), "v"(pc));)
         }
+        KIND8(10, I_OR3) KIND8(11, I_ANDOR) KIND8(12, I_MAX2) KIND8(13, I_MAX2ABS) KIND8(14, I_PKMAXI16)
+        KIND8(15, I_MAX3I) KIND8(16, I_AND) KIND8(17, I_PERM) KIND8(18, I_FMAMIX) KIND8(19, I_MED3)
+        KIND8(20, I_MIN3) KIND8(21, I_ADD3) KIND8(22, I_LSHLOR)
+        else if (KIND == 23) { REP16(asm volatile(I_CMP(0) I_CMP(1) I_CMP(2) I_CMP(3) I_CMP(4) I_CMP(5) I_CMP(6) I_CMP(7)
+                         : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3), "+v"(a4), "+v"(a5), "+v"(a6), "+v"(a7) : "v"(b), "v"(c) : "vcc");) }
     }
     float r = a0 + a1 + a2 + a3 + a4 + a5 + a6 + a7 + p0.x + p0.y + p1.x + p1.y + p2.x + p2.y + p3.x + p3.y;
     if (r == 12345.678f) out[threadIdx.x] = r;
@@ -58,7 +82,7 @@ static void run(const char *name, double flop_per_line, int lines_vinst)
     hipDeviceProp_t p;
     hipGetDeviceProperties(&p, 0);
     cus = p.multiProcessorCount;
-    for (int wps = 1; wps <= 8; wps *= 2) {
+    for (int wps = 2; wps <= 8; wps *= 4) {
         int blocks = cus * wps;   // 256 threads = 1 wave per SIMD per block
         int iters = 4000;
         hipLaunchKernelGGL(k<KIND>, dim3(blocks), dim3(256), 0, 0, out, 100, 1.0f);
@@ -88,5 +112,19 @@ int main()
     run<3>("v_max3_f32 |abs|", 16, 8);
     run<4>("v_mul_f32", 8, 8);
     run<5>("v_fma_f32 sgpr-src", 16, 8);
+    run<10>("v_or3_b32", 8, 8);
+    run<11>("v_and_or_b32", 8, 8);
+    run<12>("v_max_f32 (vop2)", 8, 8);
+    run<13>("v_max_f32_e64 |abs|", 8, 8);
+    run<14>("v_pk_max_i16", 8, 8);
+    run<15>("v_max3_i32", 8, 8);
+    run<16>("v_and_b32", 8, 8);
+    run<17>("v_perm_b32", 8, 8);
+    run<18>("v_fma_f32 acc-last", 16, 8);
+    run<19>("v_med3_f32", 8, 8);
+    run<20>("v_min3_f32", 8, 8);
+    run<21>("v_add3_u32", 8, 8);
+    run<22>("v_lshl_or_b32", 8, 8);
+    run<23>("v_cmp_ge_f32 (vopc)", 8, 8);
     return 0;
 }
