@@ -31,7 +31,7 @@ import numpy as np
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
-from cudaraytracing_amd import abi, configs  # noqa: E402
+from cudaraytracing_amd import abi, configs, sharding  # noqa: E402
 from cudaraytracing_amd.host import Camera, DeviceBuffer, generate_scene  # noqa: E402
 
 FP32_VECTOR_PEAK_TFLOPS = 157.3     # MI355X vector FP32 peak (256 CU x 4 SIMD x 64 FLOP/clk x 2.4 GHz)
@@ -47,7 +47,7 @@ def parse():
     ap.add_argument("--config", default="c3_3840x2160_n1024", choices=sorted(configs.CONFIGS))
     ap.add_argument("--mode", default="frames", choices=["frames", "bands"])
     ap.add_argument("--sequence", action="store_true", help="animate the camera along the 300-frame path")
-    ap.add_argument("--variant", default="tiled", choices=["tiled", "tiled2", "literal"])
+    ap.add_argument("--variant", default="tiled", choices=["tiled", "tiled2", "tiled4", "tiled8", "literal"])
     ap.add_argument("--no-cpu", action="store_true", help="skip the cpu_baseline leg")
     ap.add_argument("--cpu-rows", type=int, default=0, help="rows of the frame the CPU baseline renders (0 = auto)")
     return ap.parse_args()
@@ -96,7 +96,7 @@ def main():
 
     cfg = configs.CONFIGS[args.config]
     w, h, n = cfg["width"], cfg["height"], cfg["n"]
-    variant = {"tiled": abi.VARIANT_TILED, "tiled2": abi.VARIANT_TILED2, "literal": abi.VARIANT_LITERAL}[args.variant]
+    variant = {"tiled": abi.VARIANT_TILED, "tiled2": abi.VARIANT_TILED2, "tiled4": abi.VARIANT_TILED4, "tiled8": abi.VARIANT_TILED8, "literal": abi.VARIANT_LITERAL}[args.variant]
 
     # scene resident in HBM before the timed region (SceneManager.cpp:17-24)
     pos, rad, col = generate_scene(n, cfg["seed"])
@@ -122,10 +122,9 @@ def main():
     screen = abi.RcScreen(frame.data_ptr(), w, rows, w * 16)
     stream = torch.cuda.current_stream().cuda_stream
     opts = abi.RcOpts(y_offset=y0, full_height=h, variant=variant, stream=stream)
-    gathered = None
+    full = None
     if args.mode == "bands" and world > 1 and rank == 0:
-        gathered = [torch.empty((configs.band_rows(h, world, r)[1] - configs.band_rows(h, world, r)[0], w, 4),
-                                dtype=torch.float32, device="cuda") for r in range(world)]
+        full = torch.empty((h, w, 4), dtype=torch.float32, device="cuda")
 
     def step(i):
         if args.sequence:
@@ -134,7 +133,7 @@ def main():
             scene.cam = cam.get_data()                     # SceneManager::UpdateCamera
         abi.check(lib.rc_render(C.byref(screen), C.byref(scene), C.byref(opts)), "rc_render")
         if args.mode == "bands" and world > 1:
-            dist.gather(frame, gathered, dst=0)
+            sharding.gather_bands(frame, full, h, world, rank, dst=0)
 
     def fence():
         if world > 1:
@@ -157,10 +156,7 @@ def main():
     ev_ms = C.c_float()
     abi.check(lib.rc_event_elapsed_ms(ev0, ev1, C.byref(ev_ms)))
 
-    t = torch.tensor([dt], dtype=torch.float64, device="cuda")
-    if world > 1:
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-    dt_max = float(t.item())
+    dt_max = sharding.max_over_ranks(dt, "cuda")
 
     frames_total = args.steps * (world if args.mode == "frames" else 1)
     value = w * h * frames_total / dt_max / 1e6
@@ -186,7 +182,7 @@ def main():
             "roofline": {
                 "bound": "valu_fp32", "achieved": achieved_tflops, "peak": FP32_VECTOR_PEAK_TFLOPS, "unit": "TFLOP/s",
                 "frac": achieved_tflops / FP32_VECTOR_PEAK_TFLOPS, "traffic": None,
-                "kernel": "rc_draw_tiled<4>" if args.variant == "tiled" else args.variant,
+                "kernel": "rc_draw_tiled<P>" if args.variant == "tiled" else args.variant,
                 "kernel_ms": kernel_ms, "flop_per_test": FLOP_PER_TEST, "tests_per_launch": tests,
                 "ref_equiv_tflops_21flop": 21 * tests / (kernel_ms * 1e-3) / 1e12,
                 "hbm_write_gbs": 16.0 * w * rows / (kernel_ms * 1e-3) / 1e9, "hbm_peak_gbs": HBM_PEAK_GBS,

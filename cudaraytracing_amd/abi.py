@@ -16,6 +16,8 @@ VARIANT_AUTO = 0
 VARIANT_LITERAL = 1
 VARIANT_TILED = 2
 VARIANT_TILED2 = 3
+VARIANT_TILED8 = 4
+VARIANT_TILED4 = 5
 
 
 class RcVec3(C.Structure):

@@ -1,0 +1,82 @@
+// rc_render -- command-line front end of the ray caster (replaces the Win32/D3D11 shell of
+// main.cpp and DXManager.cpp: no window, the frame goes to a PPM file).
+//
+//   rc_render [--width W] [--height H] [--spheres N] [--seed S] [--frames F] [--variant V]
+//             [--pos x,y,z] [--rot pitch,yaw] [--out frame.ppm]
+//
+// With --frames F > 1 the camera follows the scripted 300-frame path
+// (theta = 2 pi f / 300: rotation (0.15 sin 2theta, 0.5 sin theta, 0), position
+// (6 sin theta, 1.5 sin 2theta, 20)) and the per-frame time is printed the way the reference
+// prints it (main.cpp:50), here measured with HIP events around the launch only.
+#include <cmath>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <string>
+
+#include "rc_raycaster.hpp"
+
+static bool parse3(const char *s, float *a, float *b, float *c)
+{
+    return std::sscanf(s, "%f,%f,%f", a, b, c) == 3;
+}
+
+int main(int argc, char **argv)
+{
+    int w = 1280, h = 768, n = 32 * 16, frames = 1, variant = RC_VARIANT_AUTO;   // main.cpp:32-33, SceneManager.cpp:8
+    unsigned seed = 0;
+    rc_vec3 pos{0.0f, 0.0f, 20.0f}, rot{0.0f, 0.0f, 0.0f};
+    std::string out = "frame.ppm";
+    for (int i = 1; i < argc; i++) {
+        auto need = [&](const char *flag) -> const char * {
+            if (i + 1 >= argc) { std::fprintf(stderr, "%s needs a value\n", flag); std::exit(2); }
+            return argv[++i];
+        };
+        if (!std::strcmp(argv[i], "--width")) w = std::atoi(need("--width"));
+        else if (!std::strcmp(argv[i], "--height")) h = std::atoi(need("--height"));
+        else if (!std::strcmp(argv[i], "--spheres")) n = std::atoi(need("--spheres"));
+        else if (!std::strcmp(argv[i], "--seed")) seed = (unsigned)std::strtoul(need("--seed"), nullptr, 10);
+        else if (!std::strcmp(argv[i], "--frames")) frames = std::atoi(need("--frames"));
+        else if (!std::strcmp(argv[i], "--variant")) variant = std::atoi(need("--variant"));
+        else if (!std::strcmp(argv[i], "--out")) out = need("--out");
+        else if (!std::strcmp(argv[i], "--pos")) { if (!parse3(need("--pos"), &pos.x, &pos.y, &pos.z)) return 2; }
+        else if (!std::strcmp(argv[i], "--rot")) { float z; const char *v = need("--rot");
+            if (std::sscanf(v, "%f,%f", &rot.x, &rot.y) != 2 && !parse3(v, &rot.x, &rot.y, &z)) return 2; }
+        else { std::fprintf(stderr, "unknown option %s\n", argv[i]); return 2; }
+    }
+    try {
+        rc::RayTracingKernel rtk;
+        if (!rtk.Init(w, h, n, seed)) return 1;
+        rtk.opts.variant = variant;
+        rtk.RegisterSurface();
+        rtk.sm.cam.position = pos;
+        rtk.sm.cam.SetRotation(rot);
+        rtk.sm.UpdateCamera();
+        void *e0 = nullptr, *e1 = nullptr;
+        rc::check(rc_event_create(&e0), "rc_event_create");
+        rc::check(rc_event_create(&e1), "rc_event_create");
+        for (int f = 0; f < frames; f++) {
+            if (frames > 1) {
+                const double th = 2.0 * 3.14159265358979323846 * f / 300.0;
+                rtk.sm.cam.position = rc_vec3{(float)(6.0 * std::sin(th)), (float)(1.5 * std::sin(2 * th)), 20.0f};
+                rtk.sm.cam.SetRotation(rc_vec3{(float)(0.15 * std::sin(2 * th)), (float)(0.5 * std::sin(th)), 0.0f});
+                rtk.sm.UpdateCamera();
+            }
+            rc::check(rc_event_record(e0, nullptr), "rc_event_record");
+            rtk.Run(false);
+            rc::check(rc_event_record(e1, nullptr), "rc_event_record");
+            float ms = 0.0f;
+            rc::check(rc_event_elapsed_ms(e0, e1, &ms), "rc_event_elapsed_ms");
+            std::printf("frame: %f\n", ms);
+        }
+        rtk.WritePPM(out.c_str());
+        std::printf("wrote %s (%dx%d, %d spheres)\n", out.c_str(), w, h, n);
+        rc_event_destroy(e0);
+        rc_event_destroy(e1);
+        rtk.Cleanup();
+    } catch (const std::exception &e) {
+        std::fprintf(stderr, "rc_render: %s\n", e.what());
+        return 1;
+    }
+    return 0;
+}

@@ -112,6 +112,23 @@ int rc_get_tables(float fov, int width, int full_height, const float **sx, const
     return RC_OK;
 }
 
+// compute units per device, queried once (sizes the tiled kernel's grid)
+int rc_compute_units(int dev, int *cus)
+{
+    static int cache[64];
+    static std::mutex mu;
+    std::lock_guard<std::mutex> lock(mu);
+    if (dev >= 0 && dev < 64 && cache[dev] > 0) {
+        *cus = cache[dev];
+        return RC_OK;
+    }
+    int v = 0;
+    RC_HIP(hipDeviceGetAttribute(&v, hipDeviceAttributeMultiprocessorCount, dev));
+    if (dev >= 0 && dev < 64) cache[dev] = v;
+    *cus = v;
+    return RC_OK;
+}
+
 } // namespace
 
 // ---- hot path ------------------------------------------------------------------------------
@@ -141,9 +158,11 @@ extern "C" int rc_render(const rc_screen *screen, const rc_scene *scene, const r
     int kv;
     switch (o.variant) {
     case RC_VARIANT_AUTO:
-    case RC_VARIANT_TILED: kv = RC_KVARIANT_TILED4; break;
+    case RC_VARIANT_TILED: kv = RC_KVARIANT_AUTO; break;
     case RC_VARIANT_LITERAL: kv = RC_KVARIANT_LITERAL; break;
-    case 3: kv = RC_KVARIANT_TILED2; break;   /* tuning variant: 2 pixels per lane */
+    case 3: kv = RC_KVARIANT_TILED2; break;   /* tuning: force 2 pixels per lane */
+    case 4: kv = RC_KVARIANT_TILED8; break;   /* tuning: force 8 pixels per lane */
+    case 5: kv = RC_KVARIANT_TILED4; break;   /* tuning: force 4 pixels per lane */
     default: return rc_fail_arg("unknown variant");
     }
 
@@ -173,7 +192,25 @@ extern "C" int rc_render(const rc_screen *screen, const rc_scene *scene, const r
     a.ux = scene->cam.up.x;       a.uy = scene->cam.up.y;       a.uz = scene->cam.up.z;
     a.rx = scene->cam.right.x;    a.ry = scene->cam.right.y;    a.rz = scene->cam.right.z;
 
-    hipError_t e = rc_launch_draw(a, kv, static_cast<hipStream_t>(o.stream));
+    {
+        // range in which the tiled kernel's filter bounds are proven; outside it every lane
+        // takes the exact path (same results, slower)
+        auto norm_up = [](float x, float y, float z) {
+            return (float)(sqrt((double)x * x + (double)y * y + (double)z * z) * (1.0 + 1e-6));
+        };
+        a.nF = norm_up(a.fx, a.fy, a.fz);
+        a.nR = norm_up(a.rx, a.ry, a.rz);
+        a.nU = norm_up(a.ux, a.uy, a.uz);
+        auto in_range = [](float v) { return v > 0x1p-20f && v < 0x1p20f; };
+        a.cam_ok = (in_range(a.nF) && in_range(a.nR) && in_range(a.nU) && fabsf(a.aspect) < 0x1p20f &&
+                    fabsf(a.ox) < 0x1p60f && fabsf(a.oy) < 0x1p60f && fabsf(a.oz) < 0x1p60f) ? 1 : 0;
+    }
+
+    int dev = 0, cus = 0;
+    RC_HIP(hipGetDevice(&dev));
+    rc = rc_compute_units(dev, &cus);
+    if (rc != RC_OK) return rc;
+    hipError_t e = rc_launch_draw(a, kv, cus, static_cast<hipStream_t>(o.stream));
     if (e != hipSuccess) return rc_fail_hip(e, "draw kernel launch");
     return RC_OK;
 }

@@ -4,9 +4,9 @@
 #include <stddef.h>
 #include <stdint.h>
 
-#define RC_LDS_CHUNK 2048   // spheres staged in LDS per pass (24 KiB of records + 2 KiB flags)
+#define RC_LDS_CHUNK_MAX 4096   // most spheres staged in LDS per pass (13 bytes each: 52 KiB)
 
-enum { RC_KVARIANT_LITERAL = 1, RC_KVARIANT_TILED4 = 2, RC_KVARIANT_TILED2 = 3 };
+enum { RC_KVARIANT_AUTO = 0, RC_KVARIANT_LITERAL = 1, RC_KVARIANT_TILED4 = 2, RC_KVARIANT_TILED2 = 3, RC_KVARIANT_TILED8 = 4 };
 
 // Passed by value as the kernel parameter, as the reference passes Screen and Scene
 // (kernel.cu:69).  `rows` is the number of surface rows (a band of the frame); frame row of
@@ -31,8 +31,13 @@ struct RcKernArgs {
     float fx, fy, fz;        // cam.forward
     float ux, uy, uz;        // cam.up
     float rx, ry, rz;        // cam.right
+    float nF, nR, nU;        // upper bounds of |forward|, |right|, |up| (filter range check)
+    int cam_ok;              // 0: camera basis outside the range the filter is proven for
+    // filled in by the tiled launcher
+    int lds_cap;             // spheres per LDS chunk (multiple of 16)
+    int tiles_x, tiles_y;    // workgroup tiles covering the surface
 };
 
-hipError_t rc_launch_draw(const RcKernArgs &a, int variant, hipStream_t stream);
+hipError_t rc_launch_draw(const RcKernArgs &a, int variant, int compute_units, hipStream_t stream);
 hipError_t rc_launch_rgba8(const void *surface, size_t pitch, int width, int rows, void *out,
                            size_t out_pitch, int flip, hipStream_t stream);

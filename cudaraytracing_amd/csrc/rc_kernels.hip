@@ -8,11 +8,11 @@
 //   rc_draw_tiled<P>  (default)  one wave64 owns an (8P x 8) pixel tile, P pixels per lane.
 //     Per workgroup the sphere list is reduced ONCE to a 12-byte record per sphere, staged
 //     in LDS and read back as wave-wide broadcasts.  For each (pixel, sphere) pair the
-//     inner loop evaluates a conservative FMA filter |v^ . d| >= 1 (3 VALU ops + half a
-//     v_max3 per test); only pairs the filter cannot rule out are re-tested with the
-//     reference's exact, separately rounded arithmetic.  The filter can only say "maybe",
-//     so surfaces are bit-identical to the unfiltered evaluation (soundness argument at
-//     rc_prepass_sphere below).
+//     inner loop evaluates a conservative, separable FMA filter (one FMA shared by the
+//     lane's P pixels + one FMA + half a v_max3 per test); only pairs the filter cannot
+//     rule out are re-tested with the reference's exact, separately rounded arithmetic.
+//     The filter can only say "maybe", so surfaces are bit-identical to the unfiltered
+//     evaluation (soundness argument at rc_prepass_sphere below).
 //   rc_draw_literal   one pixel per lane, every pair evaluated exactly as kernel.cu:52-67.
 //     Kept as the in-library cross-check and as the "straight translation" speed baseline.
 //
@@ -30,10 +30,8 @@
 
 namespace {
 
-constexpr int kWave = 64;
 constexpr int kBlock = 256;            // 4 waves, one per SIMD; >= 2 workgroups per CU
 constexpr int kGroup = 4;              // spheres per filter group (48 bytes of LDS)
-constexpr int kChunk = RC_LDS_CHUNK;   // spheres staged per pass
 
 // ---------------------------------------------------------------------------------------
 // Exact arithmetic (reference order of operations)
@@ -166,125 +164,225 @@ namespace {
 // Tiled kernel
 // ---------------------------------------------------------------------------------------
 
-// Filter record of one sphere: v^ = v * k with k = 1/sqrt(c - m), m = 2^-17 * (v.v).
+// Separable conservative filter.
 //
-// Soundness (u = 2^-24; L = |v|; A = sum |v_i d_i| <= L|d|; |d|^2 < 1 + 2^-19 checked per
-// lane).  The exact test hits only if fl(beta^2) >= c with beta = b/2 the separately
-// rounded dot product, so beta^2 >= c(1-u).  The filter value F = fma(v^z,dz,fma(v^y,dy,
-// v^x*dx)) satisfies F = k(t + e) with t the real dot product, |e| <= 4.01uA, and
-// |beta - t| <= 3.01uA, hence F^2 >= k^2 (c - 15.3u L^2).  With k^2 = (1+-8.1u)/(c - m)
-// and m = 128u (v.v) >= 127u L^2 this gives F^2 >= 1 whenever the exact test hits.
-// Spheres for which that argument does not apply (c - m <= 0: camera inside or within
-// 2^-17 of the surface; |v|^2 outside [2^-100, 2^100]; NaN/Inf anywhere; v^ not < 2^60)
-// are flagged "always": their record is zero and they are always re-tested exactly.
-__device__ __forceinline__ void rc_prepass_sphere(const RcKernArgs &a, int i,
-                                                  float &hx, float &hy, float &hz, bool &always)
+// With a = sin(xa)*aspect and b = sin(ya) the un-normalised ray is q = F + a R + b U
+// (kernel.cu:49) and d = q/|q|, so for a sphere with v = o - pos (kernel.cu:53)
+//
+//      -(v.d) * k  =  (alpha + b*gamma + a*beta) / |q|,      alpha = -k (v.F),  beta = -k (v.R),
+//                                                             gamma = -k (v.U)
+//
+// alpha, beta, gamma depend on the sphere only (computed once per workgroup), a on the pixel
+// column, b on the pixel row, len = |q| on the pixel.  A pixel can hit a sphere it is outside
+// of only if -(v.d) >= sqrt(c) up to rounding (c = v.v - r*r, the discriminant test of
+// kernel.cu:58-59 with b < 0; for b >= 0 and c > 0 both roots are negative and kernel.cu:91
+// rejects them).  The filter flags the pair when
+//
+//      T = fma(a, beta, fma(b, gamma, alpha))  >=  len .
+//
+// Soundness (u = 2^-24, L = |v|, Q = |F| + |a||R| + |b||U| <= 4 len, checked per lane):
+//  * the exact test hits only if -(v.d) >= sqrt(c)(1-u) - 3.01uL (c as the reference rounds it);
+//  * the reference's float q, len, 1/len, d differ from the real ones by <= 4uQ, 2.5u, u, u
+//    (relative), so -(v.q) >= len (sqrt(c)(1-2u) - 4.03uL);
+//  * T differs from k(-(v.q)) by <= 12ukLQ <= 48uk L len: 5u for the float records (dot product
+//    3u, k and its product 2u), u for a, 2u for the two fma roundings, 4u for q itself;
+//  hence T >= k len (sqrt(c)(1-2u) - 52.1uL).  The record uses
+//      k = 1 / thr,   thr = sqrt(c)(1 - 2^-19) - 2^-17 sqrt(v.v)   (all binary32, <= 3u error)
+//  which is below sqrt(c)(1-5u) - 64uL, so k(...) >= 1 and T >= len whenever the exact test hits.
+// Spheres where thr <= 0 or any quantity leaves the range in which these bounds hold (camera
+// inside or within ~1e-5 relative of the surface, non-finite data, |v|^2 outside [2^-80, 2^80],
+// |record| >= 2^40) are flagged "always" and re-tested exactly every time; lanes whose ray
+// set-up is out of range (Q > 4 len, len outside [2^-20, 2^20], degenerate camera basis)
+// bypass the filter too.
+struct RcRecord { float alpha, gamma, beta; bool always; };
+
+constexpr float kNever = -1.0e30f;   // record value that can never reach len
+
+__device__ __forceinline__ RcRecord rc_prepass_sphere(const RcKernArgs &a, int i)
 {
     float px = a.position[3 * i + 0], py = a.position[3 * i + 1], pz = a.position[3 * i + 2];
     float r = a.radius[i];
     float vx = a.ox - px, vy = a.oy - py, vz = a.oz - pz;
     float vv = (vx * vx + vy * vy) + vz * vz;
-    float c = vv - r * r;
-    float cm = c - vv * 0x1p-17f;
-    always = !(cm > 0.0f) || !(vv < 0x1p100f) || !(vv > 0x1p-100f);
-    float k = 1.0f / sqrtf(cm);
-    hx = vx * k; hy = vy * k; hz = vz * k;
-    always = always || !(fabsf(hx) < 0x1p60f) || !(fabsf(hy) < 0x1p60f) || !(fabsf(hz) < 0x1p60f);
-    if (always) { hx = 0.0f; hy = 0.0f; hz = 0.0f; }
+    float c = vv - r * r;                                   // the reference's c, as rounded
+    float thr = sqrtf(c) * (1.0f - 0x1p-19f) - 0x1p-17f * sqrtf(vv);
+    RcRecord rec;
+    rec.always = !(c > 0.0f) || !(thr > 0.0f) || !(vv < 0x1p80f) || !(vv > 0x1p-80f);
+    float k = 1.0f / thr;
+    float vF = __builtin_fmaf(vz, a.fz, __builtin_fmaf(vy, a.fy, vx * a.fx));
+    float vR = __builtin_fmaf(vz, a.rz, __builtin_fmaf(vy, a.ry, vx * a.rx));
+    float vU = __builtin_fmaf(vz, a.uz, __builtin_fmaf(vy, a.uy, vx * a.ux));
+    rec.alpha = -k * vF;
+    rec.beta = -k * vR;
+    rec.gamma = -k * vU;
+    rec.always = rec.always || !(fabsf(rec.alpha) < 0x1p40f) || !(fabsf(rec.beta) < 0x1p40f) ||
+                 !(fabsf(rec.gamma) < 0x1p40f);
+    if (rec.always) { rec.alpha = kNever; rec.beta = 0.0f; rec.gamma = 0.0f; }
+    return rec;
 }
 
+typedef float rc_f2 __attribute__((ext_vector_type(2)));
+
+__device__ __forceinline__ rc_f2 rc_fma2(rc_f2 x, rc_f2 y, rc_f2 z) { return __builtin_elementwise_fma(x, y, z); }
+
+constexpr int kBlockSpheres = 16;                       // spheres between two flag checks
+constexpr int kGroupsPerBlock = kBlockSpheres / kGroup;
+
+// LDS image of a chunk of `cap` spheres (cap a multiple of 16):
+//   float4 rec[cap/4*3]   per group of 4 spheres {alpha0..3}{gamma0..3}{beta0..3}
+//   uint   flag[cap/4]    per group, byte s = "always" flag of sphere s
+//   int    has_always
+__host__ __device__ constexpr size_t rc_lds_bytes(int cap) { return (size_t)cap * 12 + (size_t)cap + 16; }
+
 template <int P>
-__device__ __forceinline__ void rc_tiled_body(const RcKernArgs &a, float4 *s_rec,
-                                              unsigned char *s_flag, int *s_has_always)
+__device__ __forceinline__ void rc_tiled_body(const RcKernArgs &a, char *lds)
 {
     constexpr int TW = 8 * P;   // wave tile width in pixels
+    const int cap = a.lds_cap;
+    float4 *s_rec = reinterpret_cast<float4 *>(lds);
+    unsigned *s_flag = reinterpret_cast<unsigned *>(lds + (size_t)cap * 12);
+    int *s_has_always = reinterpret_cast<int *>(lds + (size_t)cap * 13);
+
     const int tid = threadIdx.x;
     const int wave = tid >> 6, lane = tid & 63;
     const int lx = lane & 7, ly = lane >> 3;
-    // workgroup tile: 2 x 2 waves = (16P) x 16 pixels
-    const int x0 = blockIdx.x * (2 * TW) + (wave & 1) * TW + lx;
-    const int row = blockIdx.y * 16 + (wave >> 1) * 8 + ly;
-    const int rowc = min(row, a.rows - 1);
 
-    float dx[P], dy[P], dz[P], minDist[P];
-    int idx[P];
-    float force = 0.0f;
-    const float sy = a.sin_y[rowc + a.y_offset];
-#pragma unroll
-    for (int p = 0; p < P; p++) {
-        int xc = min(x0 + 8 * p, a.width - 1);
-        rc_ray_dir(a, a.sin_x[xc], sy, dx[p], dy[p], dz[p]);
-        float dd = (dx[p] * dx[p] + dy[p] * dy[p]) + dz[p] * dz[p];
-        // directions that are not unit vectors (degenerate camera) bypass the filter
-        if (!(dd < 1.0f + 0x1p-19f) || !(dd > 1.0f - 0x1p-19f)) force = __builtin_inff();
-        minDist[p] = 10000.0f;
-        idx[p] = -1;
-    }
-    const bool lane_forced = force > 0.0f;
+    // One workgroup per (16P x 16)-pixel tile.  Many short workgroups beat fewer long ones
+    // here: hit-heavy tiles cost more than empty ones and the hardware dispatcher evens that
+    // out (2-8 tiles per workgroup measured 5-25 % slower at 3840x2160 x 1024 spheres even
+    // though the sphere records would be built less often).
+    {
+        const int tile = blockIdx.x;
+        const int tyi = tile / a.tiles_x, txi = tile - tyi * a.tiles_x;
+        const int x0 = txi * (2 * TW) + (wave & 1) * TW + lx;
+        const int row = tyi * 16 + (wave >> 1) * 8 + ly;
+        const int rowc = min(row, a.rows - 1);
 
-    for (int base = 0; base < a.n; base += kChunk) {
-        const int cn = min(a.n - base, kChunk);
-        const int cn4 = (cn + kGroup - 1) & ~(kGroup - 1);
-        if (tid == 0) *s_has_always = 0;
-        __syncthreads();
-        {
-            float *rec = reinterpret_cast<float *>(s_rec);
-            for (int j = tid; j < cn4; j += kBlock) {
-                float hx = 0.0f, hy = 0.0f, hz = 0.0f;
-                bool always = false;
-                if (j < cn) rc_prepass_sphere(a, base + j, hx, hy, hz, always);
-                rec[3 * j + 0] = hx; rec[3 * j + 1] = hy; rec[3 * j + 2] = hz;
-                s_flag[j] = always ? 1 : 0;
-                if (always) *s_has_always = 1;
-            }
-        }
-        __syncthreads();
-        const float m0 = (*s_has_always != 0) ? __builtin_inff() : force;
-        const int ngroups = cn4 / kGroup;
-
-        for (int g = 0; g < ngroups; g++) {
-            const float4 q0 = s_rec[3 * g + 0], q1 = s_rec[3 * g + 1], q2 = s_rec[3 * g + 2];
-            const float hx[kGroup] = {q0.x, q0.w, q1.z, q2.y};
-            const float hy[kGroup] = {q0.y, q1.x, q1.w, q2.z};
-            const float hz[kGroup] = {q0.z, q1.y, q2.x, q2.w};
-            float f[kGroup][P];
-            float m = m0;
-#pragma unroll
-            for (int s = 0; s < kGroup; s++) {
-#pragma unroll
-                for (int p = 0; p < P; p++) {
-                    f[s][p] = __builtin_fmaf(hz[s], dz[p], __builtin_fmaf(hy[s], dy[p], hx[s] * dx[p]));
-                    m = fmaxf(m, fabsf(f[s][p]));
-                }
-            }
-            if (__builtin_amdgcn_ballot_w64(m >= 1.0f) != 0ull) {
-                // Rare path: some lane cannot rule out some sphere of this group.
-#pragma unroll
-                for (int s = 0; s < kGroup; s++) {
-                    const int j = kGroup * g + s;
-                    if (j >= cn) break;
-                    bool cand = lane_forced || (s_flag[j] != 0);
-#pragma unroll
-                    for (int p = 0; p < P; p++) cand = cand || (fabsf(f[s][p]) >= 1.0f);
-                    if (__builtin_amdgcn_ballot_w64(cand) == 0ull) continue;
-                    const RcExactSphere e = rc_exact_sphere(a, base + j);
-#pragma unroll
-                    for (int p = 0; p < P; p++)
-                        rc_exact_test(e, dx[p], dy[p], dz[p], base + j, minDist[p], idx[p]);
-                }
-            }
-        }
-        __syncthreads();
-    }
-
-    if (row < a.rows) {
+        float fa[P], len[P], dx[P], dy[P], dz[P], minDist[P];
+        int idx[P];
+        bool lane_forced = (a.cam_ok == 0);
+        const float sy = a.sin_y[rowc + a.y_offset];
+        const float fb = sy;
 #pragma unroll
         for (int p = 0; p < P; p++) {
-            const int x = x0 + 8 * p;
-            if (x < a.width) {
-                float r = 0.0f, g = 0.0f, b = 0.0f;
-                if (idx[p] >= 0) rc_shade(a, idx[p], minDist[p], dx[p], dy[p], dz[p], r, g, b);
-                rc_store_pixel(a, x, row, r, g, b);
+            const int xc = min(x0 + 8 * p, a.width - 1);
+            const float sx = a.sin_x[xc];
+            // kernel.cu:49 + vec3::norm, exactly (same statements as rc_ray_dir, keeping |q|)
+            float tx = a.rx * sx, ty = a.ry * sx, tz = a.rz * sx;
+            tx = tx * a.aspect; ty = ty * a.aspect; tz = tz * a.aspect;
+            float qx = a.fx + tx, qy = a.fy + ty, qz = a.fz + tz;
+            const float wx = a.ux * sy, wy = a.uy * sy, wz = a.uz * sy;
+            qx = qx + wx; qy = qy + wy; qz = qz + wz;
+            len[p] = sqrtf((qx * qx + qy * qy) + qz * qz);
+            const float inv = 1.0f / len[p];
+            dx[p] = qx * inv; dy[p] = qy * inv; dz[p] = qz * inv;
+            // filter inputs
+            fa[p] = sx * a.aspect;
+            const float Q = a.nF + fabsf(fa[p]) * a.nR + fabsf(fb) * a.nU;
+            if (!(Q <= 4.0f * len[p]) || !(len[p] > 0x1p-20f) || !(len[p] < 0x1p20f)) lane_forced = true;
+            minDist[p] = 10000.0f;
+            idx[p] = -1;
+        }
+        const rc_f2 bb = {fb, fb};
+        const unsigned long long forced_mask = __builtin_amdgcn_ballot_w64(lane_forced);
+
+        for (int base = 0; base < a.n; base += cap) {
+            const int cn = min(a.n - base, cap);
+            const int cnb = (cn + kBlockSpheres - 1) & ~(kBlockSpheres - 1);   // whole blocks
+            {
+                __syncthreads();                       // previous chunk fully consumed
+                if (tid == 0) *s_has_always = 0;
+                __syncthreads();
+                float *rec = reinterpret_cast<float *>(s_rec);
+                unsigned char *flagb = reinterpret_cast<unsigned char *>(s_flag);
+                for (int j = tid; j < cnb; j += kBlock) {
+                    RcRecord r;
+                    r.alpha = kNever; r.gamma = 0.0f; r.beta = 0.0f; r.always = false;
+                    if (j < cn) r = rc_prepass_sphere(a, base + j);
+                    float *g = rec + (j >> 2) * 12 + (j & 3);
+                    g[0] = r.alpha; g[4] = r.gamma; g[8] = r.beta;
+                    flagb[j] = r.always ? 1 : 0;
+                    if (r.always) *s_has_always = 1;
+                }
+                __syncthreads();
+            }
+            const unsigned long long flag0_mask = (*s_has_always != 0) ? ~0ull : forced_mask;
+            const int nblocks = cnb / kBlockSpheres;
+
+            for (int blk = 0; blk < nblocks; blk++) {
+                float m[P];
+#pragma unroll
+                for (int p = 0; p < P; p++) m[p] = -__builtin_inff();
+#pragma unroll
+                for (int g = 0; g < kGroupsPerBlock; g++) {
+                    const float4 A = s_rec[(blk * kGroupsPerBlock + g) * 3 + 0];
+                    const float4 G = s_rec[(blk * kGroupsPerBlock + g) * 3 + 1];
+                    const float4 B = s_rec[(blk * kGroupsPerBlock + g) * 3 + 2];
+                    const rc_f2 r01 = rc_fma2(bb, rc_f2{G.x, G.y}, rc_f2{A.x, A.y});
+                    const rc_f2 r23 = rc_fma2(bb, rc_f2{G.z, G.w}, rc_f2{A.z, A.w});
+#pragma unroll
+                    for (int p = 0; p < P; p++) {
+                        const rc_f2 aa = {fa[p], fa[p]};
+                        const rc_f2 t01 = rc_fma2(aa, rc_f2{B.x, B.y}, r01);
+                        const rc_f2 t23 = rc_fma2(aa, rc_f2{B.z, B.w}, r23);
+                        m[p] = fmaxf(fmaxf(m[p], t01.x), t01.y);
+                        m[p] = fmaxf(fmaxf(m[p], t23.x), t23.y);
+                    }
+                }
+                unsigned long long flagged = flag0_mask;          // wave-wide, lives in SGPRs
+#pragma unroll
+                for (int p = 0; p < P; p++) flagged |= __builtin_amdgcn_ballot_w64(m[p] >= len[p]);
+                if (flagged != 0ull) {
+                    // Rare path: some lane cannot rule out some sphere of this block.  Redo the
+                    // filter group by group (same fma, same bits), this time keeping one
+                    // wave-wide mask per sphere, and run the reference's exact test for every
+                    // sphere some lane still flags.
+#pragma nounroll
+                    for (int g = 0; g < kGroupsPerBlock; g++) {
+                        const int gi = blk * kGroupsPerBlock + g;
+                        if (gi * kGroup >= cn) break;
+                        const float4 A = s_rec[gi * 3 + 0];
+                        const float4 G = s_rec[gi * 3 + 1];
+                        const float4 B = s_rec[gi * 3 + 2];
+                        const unsigned fl = __builtin_amdgcn_readfirstlane(s_flag[gi]);
+                        const rc_f2 r01 = rc_fma2(bb, rc_f2{G.x, G.y}, rc_f2{A.x, A.y});
+                        const rc_f2 r23 = rc_fma2(bb, rc_f2{G.z, G.w}, rc_f2{A.z, A.w});
+                        unsigned long long cm[kGroup];
+#pragma unroll
+                        for (int s = 0; s < kGroup; s++) cm[s] = ((fl >> (8 * s)) & 0xffu) ? ~0ull : forced_mask;
+#pragma unroll
+                        for (int p = 0; p < P; p++) {
+                            const rc_f2 aa = {fa[p], fa[p]};
+                            const rc_f2 t01 = rc_fma2(aa, rc_f2{B.x, B.y}, r01);
+                            const rc_f2 t23 = rc_fma2(aa, rc_f2{B.z, B.w}, r23);
+                            cm[0] |= __builtin_amdgcn_ballot_w64(t01.x >= len[p]);
+                            cm[1] |= __builtin_amdgcn_ballot_w64(t01.y >= len[p]);
+                            cm[2] |= __builtin_amdgcn_ballot_w64(t23.x >= len[p]);
+                            cm[3] |= __builtin_amdgcn_ballot_w64(t23.y >= len[p]);
+                        }
+#pragma unroll
+                        for (int s = 0; s < kGroup; s++) {
+                            const int j = gi * kGroup + s;
+                            if (cm[s] == 0ull || j >= cn) continue;
+                            const RcExactSphere e = rc_exact_sphere(a, base + j);
+#pragma unroll
+                            for (int p = 0; p < P; p++)
+                                rc_exact_test(e, dx[p], dy[p], dz[p], base + j, minDist[p], idx[p]);
+                        }
+                    }
+                }
+            }
+        }
+
+        if (row < a.rows) {
+#pragma unroll
+            for (int p = 0; p < P; p++) {
+                const int x = x0 + 8 * p;
+                if (x < a.width) {
+                    float r = 0.0f, g = 0.0f, b = 0.0f;
+                    if (idx[p] >= 0) rc_shade(a, idx[p], minDist[p], dx[p], dy[p], dz[p], r, g, b);
+                    rc_store_pixel(a, x, row, r, g, b);
+                }
             }
         }
     }
@@ -295,10 +393,8 @@ __device__ __forceinline__ void rc_tiled_body(const RcKernArgs &a, float4 *s_rec
 template <int P>
 __global__ __launch_bounds__(256) void rc_draw_tiled(RcKernArgs a)
 {
-    __shared__ float4 s_rec[kChunk / kGroup * 3];
-    __shared__ unsigned char s_flag[kChunk];
-    __shared__ int s_has_always;
-    rc_tiled_body<P>(a, s_rec, s_flag, &s_has_always);
+    extern __shared__ __attribute__((aligned(16))) char rc_lds[];
+    rc_tiled_body<P>(a, rc_lds);
 }
 
 // float RGBA -> RGBA8 (the display step that follows the path in the reference)
@@ -318,19 +414,43 @@ __global__ __launch_bounds__(256) void rc_rgba8_kernel(const char *surface, size
 // Launchers (host)
 // ---------------------------------------------------------------------------------------
 
-hipError_t rc_launch_draw(const RcKernArgs &a, int variant, hipStream_t stream)
+template <int P>
+static long long rc_tile_count(const RcKernArgs &a)
 {
+    return (long long)((a.width + 16 * P - 1) / (16 * P)) * ((a.rows + 15) / 16);
+}
+
+template <int P>
+static hipError_t rc_launch_tiled(RcKernArgs a, hipStream_t stream)
+{
+    // LDS chunk: the whole scene when it fits (rounded up to whole 16-sphere blocks)
+    const int n16 = ((a.n > 0 ? a.n : 1) + kBlockSpheres - 1) & ~(kBlockSpheres - 1);
+    a.lds_cap = n16 < RC_LDS_CHUNK_MAX ? n16 : RC_LDS_CHUNK_MAX;
+    a.tiles_x = (a.width + 16 * P - 1) / (16 * P);
+    a.tiles_y = (a.rows + 15) / 16;
+    const unsigned grid = (unsigned)rc_tile_count<P>(a);
+    hipLaunchKernelGGL(rc_draw_tiled<P>, dim3(grid), dim3(256), rc_lds_bytes(a.lds_cap), stream, a);
+    return hipGetLastError();
+}
+
+hipError_t rc_launch_draw(const RcKernArgs &a, int variant, int compute_units, hipStream_t stream)
+{
+    if (compute_units <= 0) compute_units = 256;
     if (variant == RC_KVARIANT_LITERAL) {
         dim3 grid((a.width + 63) / 64, (a.rows + 3) / 4);
         hipLaunchKernelGGL(rc_draw_literal, grid, dim3(256), 0, stream, a);
-    } else if (variant == RC_KVARIANT_TILED2) {
-        dim3 grid((a.width + 31) / 32, (a.rows + 15) / 16);
-        hipLaunchKernelGGL(rc_draw_tiled<2>, grid, dim3(256), 0, stream, a);
-    } else {
-        dim3 grid((a.width + 63) / 64, (a.rows + 15) / 16);
-        hipLaunchKernelGGL(rc_draw_tiled<4>, grid, dim3(256), 0, stream, a);
+        return hipGetLastError();
     }
-    return hipGetLastError();
+    if (variant == RC_KVARIANT_TILED2) return rc_launch_tiled<2>(a, stream);
+    if (variant == RC_KVARIANT_TILED4) return rc_launch_tiled<4>(a, stream);
+    if (variant == RC_KVARIANT_TILED8) return rc_launch_tiled<8>(a, stream);
+    // Automatic: more pixels per lane share more of the per-sphere work, but the frame must
+    // still cut into enough workgroups to fill the chip (>= 5 per CU; measured crossovers:
+    // 1280x768 -> 2, 1920x1080 -> 4, 3840x2160 and up -> 8 pixels per lane).
+    const long long want = 5LL * compute_units;
+    if (rc_tile_count<8>(a) >= want) return rc_launch_tiled<8>(a, stream);
+    if (rc_tile_count<4>(a) >= want) return rc_launch_tiled<4>(a, stream);
+    return rc_launch_tiled<2>(a, stream);
 }
 
 hipError_t rc_launch_rgba8(const void *surface, size_t pitch, int width, int rows, void *out,

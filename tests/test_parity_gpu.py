@@ -18,7 +18,7 @@ from gpu_util import GpuScene, assert_same_bits, gpu_render, pixels
 
 pytestmark = pytest.mark.gpu
 
-VARIANTS = [abi.VARIANT_TILED, abi.VARIANT_TILED2, abi.VARIANT_LITERAL]
+VARIANTS = [abi.VARIANT_TILED, abi.VARIANT_TILED2, abi.VARIANT_TILED4, abi.VARIANT_TILED8, abi.VARIANT_LITERAL]
 
 
 def _frame(oracle, name):
@@ -52,7 +52,7 @@ def test_reference_known_answers_on_gpu(oracle, ref_kat, kat_scene, variant):
 
 @pytest.mark.parametrize("variant", VARIANTS)
 @pytest.mark.parametrize("w,h,n", [(333, 77, 5), (1, 1, 3), (65, 17, 1), (640, 480, 0), (31, 9, 7),
-                                    (200, 120, 2049), (96, 64, 4100)])
+                                    (200, 120, 2049), (96, 64, 4100), (64, 48, 8200)])
 def test_ragged_sizes_and_counts(oracle, w, h, n, variant):
     pos, rad, col = oracle.generate_scene(n, 3)
     cam = oracle.camera_data((0.5, -0.25, 21.0), (0.05, 0.1, 0.0), w, h)
@@ -220,6 +220,28 @@ def test_dropin_execute_kernel_from_reference_call_site(oracle, tmp_path):
     pos, rad, col = oracle.generate_scene(n, seed)
     cam = oracle.camera_data((0, 0, 20), (0, 0, 0), w, h)
     assert_same_bits(got, oracle.render(pos, rad, col, cam, w, h), "drop-in execute_kernel")
+
+
+def test_cli_writes_reference_exact_ppm(oracle, tmp_path):
+    """The C++ host layer (Camera / SceneManager / RayTracingKernel mirrors + rc_render CLI)."""
+    exe = os.path.join(ROOT, "cudaraytracing_amd", "rc_render")
+    if not os.path.exists(exe):
+        pytest.fail("cudaraytracing_amd/rc_render missing: run `python -m cudaraytracing_amd.build`")
+    w, h, n = 320, 200, 77
+    out = tmp_path / "f.ppm"
+    r = subprocess.run([exe, "--width", str(w), "--height", str(h), "--spheres", str(n), "--seed", "4",
+                        "--pos", "1,0.5,19", "--rot", "0.1,-0.2", "--out", str(out)],
+                       capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, r.stdout + r.stderr
+    assert "frame:" in r.stdout
+    data = out.read_bytes()
+    head = f"P6\n{w} {h}\n255\n".encode()
+    assert data.startswith(head)
+    img = np.frombuffer(data[len(head):], np.uint8).reshape(h, w, 3)
+    pos, rad, col = oracle.generate_scene(n, 4)
+    cam = oracle.camera_data((1, 0.5, 19), (0.1, -0.2, 0), w, h)
+    want = oracle.to_rgba8(oracle.render(pos, rad, col, cam, w, h), flip=True)
+    assert np.array_equal(img, want[..., :3])
 
 
 def test_argument_validation_on_device(rclib):

@@ -1,0 +1,63 @@
+"""The N>1 path on CPU: world_size-2 (and 3) gloo processes shard a frame into row bands,
+render their band (with the oracle standing in for the GPU renderer: same y_offset /
+full_height contract as rc_render) and assemble it with sharding.gather_bands; frames mode
+deals frames round-robin.  The assembled frame must equal the single-process frame bit for bit."""
+import os
+import socket
+
+import numpy as np
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+from cudaraytracing_amd import configs, sharding
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def _worker(rank, world, port, w, h, n, out_path):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        from oracle import binding as ob
+        pos, rad, col = ob.generate_scene(n, 0)
+        cam = ob.camera_data((0, 0, 20), (0.05, -0.1, 0), w, h)
+        b, e = configs.band_rows(h, world, rank)
+        band = ob.render(pos, rad, col, cam, w, e - b, y_offset=b, full_height=h, threads=2)
+        full = torch.zeros((h, w, 4), dtype=torch.float32) if rank == 0 else None
+        sharding.gather_bands(torch.from_numpy(band), full, h, world, rank, dst=0)
+        t = sharding.max_over_ranks(float(rank + 1), "cpu")
+        assert t == float(world)
+        dist.barrier()
+        if rank == 0:
+            np.save(out_path, full.numpy())
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("world,h", [(2, 96), (3, 100)])
+def test_band_gather_gloo(oracle, tmp_path, world, h):
+    w, n = 128, 40
+    out = str(tmp_path / "full.npy")
+    mp.spawn(_worker, args=(world, _free_port(), w, h, n, out), nprocs=world, join=True)
+    got = np.load(out)
+    pos, rad, col = oracle.generate_scene(n, 0)
+    cam = oracle.camera_data((0, 0, 20), (0.05, -0.1, 0), w, h)
+    want = oracle.render(pos, rad, col, cam, w, h)
+    assert np.array_equal(got.view(np.uint32), want.view(np.uint32))
+
+
+def test_frames_round_robin():
+    for world in (1, 2, 4, 8):
+        seen = sorted(f for r in range(world) for f in sharding.frames_for_rank(300, world, r))
+        assert seen == list(range(300))
+        sizes = [len(sharding.frames_for_rank(300, world, r)) for r in range(world)]
+        assert max(sizes) - min(sizes) <= 1
