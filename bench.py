@@ -163,6 +163,18 @@ def main():
     kernel_ms = ev_ms.value / args.steps           # HIP events on the launch stream, this rank
     tests = w * rows * n
     achieved_tflops = FLOP_PER_TEST * tests / (kernel_ms * 1e-3) / 1e12
+    # what the tiled kernel executes per test: (1 + 1/P) FMA (2 FLOP) + one max input (1 FLOP)
+    ppl = 8 if w * rows >= 5 * 256 * 128 * 16 else (4 if w * rows >= 5 * 256 * 64 * 16 else 2)
+    ppl = {"tiled2": 2, "tiled4": 4, "tiled8": 8}.get(args.variant, ppl)
+    executed_flop = 21.0 if args.variant == "literal" else 2.0 * (1.0 + 1.0 / ppl) + 1.0
+    traffic = None
+    try:
+        with open(os.path.join(ROOT, "profiles", "hbm_traffic.json")) as f:
+            t = json.load(f).get(args.config)
+        if t and args.variant == "tiled" and rows == h:
+            traffic = t["write_bytes"] + t["read_bytes"]
+    except OSError:
+        pass
 
     if rank == 0:
         cu, khz, lds = C.c_int(), C.c_int(), C.c_size_t()
@@ -181,7 +193,12 @@ def main():
             "frame_ms": kernel_ms,
             "roofline": {
                 "bound": "valu_fp32", "achieved": achieved_tflops, "peak": FP32_VECTOR_PEAK_TFLOPS, "unit": "TFLOP/s",
-                "frac": achieved_tflops / FP32_VECTOR_PEAK_TFLOPS, "traffic": None,
+                "frac": achieved_tflops / FP32_VECTOR_PEAK_TFLOPS, "traffic": traffic,
+                "traffic_note": "HBM bytes per launch from rocprofv3 PMC passes recorded in profiles/hbm_traffic.json; algorithmic bytes = 16*W*H",
+                "algorithmic_bytes": 16 * w * rows,
+                "executed_flop_per_test": executed_flop,
+                "executed_tflops": executed_flop * tests / (kernel_ms * 1e-3) / 1e12,
+                "executed_frac": executed_flop * tests / (kernel_ms * 1e-3) / 1e12 / FP32_VECTOR_PEAK_TFLOPS,
                 "kernel": "rc_draw_tiled<P>" if args.variant == "tiled" else args.variant,
                 "kernel_ms": kernel_ms, "flop_per_test": FLOP_PER_TEST, "tests_per_launch": tests,
                 "ref_equiv_tflops_21flop": 21 * tests / (kernel_ms * 1e-3) / 1e12,
