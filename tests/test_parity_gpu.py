@@ -124,6 +124,47 @@ def test_degenerate_camera_vectors(oracle, variant):
         assert_same_bits(got, want, tweak)
 
 
+def test_random_scenes_and_cameras_stress(oracle):
+    """Filter soundness, empirically: 40 random scenes with cameras near, inside and far from
+    the sphere cloud, arbitrary rotations and radii over four orders of magnitude."""
+    rng = np.random.default_rng(2024)
+    w, h = 416, 234
+    for it in range(40):
+        n = int(rng.integers(1, 400))
+        pos = rng.uniform(-12, 12, (n, 3)).astype(np.float32)
+        rad = (10.0 ** rng.uniform(-3, 1, n)).astype(np.float32)
+        col = rng.uniform(0, 1, (n, 3)).astype(np.float32)
+        if it % 3 == 0:
+            cpos = tuple(rng.uniform(-12, 12, 3))                    # inside the cloud
+        elif it % 3 == 1:
+            k = int(rng.integers(n))                                 # hugging one sphere
+            dirv = rng.normal(size=3); dirv /= np.linalg.norm(dirv)
+            cpos = tuple(pos[k] + dirv * rad[k] * rng.choice([0.5, 0.999999, 1.0, 1.000001, 1.00001, 1.01, 2.0]))
+        else:
+            cpos = tuple(rng.uniform(-60, 60, 3))
+        rot = (float(rng.uniform(-3.2, 3.2)), float(rng.uniform(-3.2, 3.2)), 0.0)
+        cam = oracle.camera_data(cpos, rot, w, h)
+        want = oracle.render(pos, rad, col, cam, w, h)
+        variant = [abi.VARIANT_TILED2, abi.VARIANT_TILED4, abi.VARIANT_TILED8][it % 3]
+        got = pixels(gpu_render(pos, rad, col, cam, w, h, variant=variant), w)
+        assert_same_bits(got, want, f"stress scene {it} (n={n}, cam={cpos}, rot={rot})")
+
+
+@pytest.mark.parametrize("scale", [1e-12, 1e-6, 1e-3, 1e3, 1e6, 1e12, 1e18])
+def test_scene_scale_extremes(oracle, scale):
+    """Coordinates from 1e-12 to 1e18: the filter's range checks must hand over to the exact
+    path wherever its error bounds stop holding (the 1e-6 offset and the 10000 cut-off of
+    kernel.cu:61,85 are not scale-free, so the images differ per scale; GPU == oracle always)."""
+    pos, rad, col = oracle.generate_scene(120, 11)
+    s = np.float32(scale)
+    w, h = 320, 180
+    cam = oracle.camera_data(tuple(np.float32([0.3, -0.2, 20.0]) * s), (0.02, 0.03, 0), w, h)
+    want = oracle.render(pos * s, rad * s, col, cam, w, h)
+    for variant in (abi.VARIANT_TILED4, abi.VARIANT_TILED8):
+        got = pixels(gpu_render(pos * s, rad * s, col, cam, w, h, variant=variant), w)
+        assert_same_bits(got, want, f"scale {scale}")
+
+
 def test_pitch_padding_untouched(oracle):
     pos, rad, col = oracle.generate_scene(16, 1)
     w, h = 100, 40
