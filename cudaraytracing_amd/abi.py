@@ -39,14 +39,26 @@ class RcScreen(C.Structure):
                 ("pitch", C.c_size_t)]
 
 
+class RcExt(C.Structure):
+    """EXT-mode additions (plane, point light, Phong, shadows); no counterpart in the reference."""
+    _fields_ = [("plane_normal", RcVec3), ("plane_h", C.c_float), ("plane_color", RcVec3),
+                ("light_pos", RcVec3), ("specular", C.c_float), ("shininess_log2", C.c_int),
+                ("has_plane", C.c_int), ("shadows", C.c_int)]
+
+
 class RcOpts(C.Structure):
     _fields_ = [("y_offset", C.c_int), ("full_height", C.c_int), ("variant", C.c_int),
-                ("reserved0", C.c_int), ("stream", C.c_void_p), ("rgba8", C.c_void_p),
-                ("rgba8_pitch", C.c_size_t), ("rgba8_flip", C.c_int), ("reserved1", C.c_int)]
+                ("mode", C.c_int), ("stream", C.c_void_p), ("rgba8", C.c_void_p),
+                ("rgba8_pitch", C.c_size_t), ("rgba8_flip", C.c_int), ("reserved1", C.c_int),
+                ("ext", C.POINTER(RcExt))]
+
+
+MODE_REF = 0
+MODE_EXT = 1
 
 
 assert C.sizeof(RcVec3) == 12 and C.sizeof(RcCamera) == 56
-assert C.sizeof(RcScene) == 88 and C.sizeof(RcScreen) == 24
+assert C.sizeof(RcScene) == 88 and C.sizeof(RcScreen) == 24 and C.sizeof(RcExt) == 56
 
 # every symbol include/rc_abi.h declares: name -> (restype, argtypes)
 SYMBOLS = {

@@ -23,6 +23,11 @@ for _c in CONFIGS.values():
     _c.setdefault("position", DEFAULT_POSITION)
     _c.setdefault("rotation", DEFAULT_ROTATION)
 
+# EXT-mode additions used by the benchmark configurations that ask for "1 plane, 1 point light,
+# Phong + hard shadows": floor plane y = -6, light above and in front of the sphere cloud.
+DEFAULT_EXT = dict(plane_normal=(0.0, 1.0, 0.0), plane_h=-6.0, plane_color=(0.6, 0.6, 0.55),
+                   light_pos=(8.0, 14.0, 12.0), specular=0.4, shininess_log2=5, has_plane=1, shadows=1)
+
 SEQUENCE_FRAMES = 300
 SEQUENCE = dict(width=3840, height=2160, n=1024, seed=0, frames=SEQUENCE_FRAMES)
 

@@ -23,6 +23,7 @@ static_assert(sizeof(rc_vec3) == 12, "vec3.h:6-10 layout");
 static_assert(sizeof(rc_camera) == 56, "Camera.h:8-19 layout");
 static_assert(sizeof(rc_scene) == 88, "Scene.h:4-13 layout");
 static_assert(sizeof(rc_screen) == 24, "Screen.h:3-9 layout");
+static_assert(sizeof(rc_ext) == 56, "rc_ext layout");
 static_assert(offsetof(rc_scene, position) == 8 && offsetof(rc_scene, radius) == 16 &&
               offsetof(rc_scene, color) == 24 && offsetof(rc_scene, cam) == 32, "Scene.h field offsets");
 static_assert(offsetof(rc_screen, width) == 8 && offsetof(rc_screen, height) == 12 &&
@@ -155,6 +156,12 @@ extern "C" int rc_render(const rc_screen *screen, const rc_scene *scene, const r
                     (reinterpret_cast<uintptr_t>(o.rgba8) & 3) != 0))
         return rc_fail_arg("rgba8 surface must be 4-byte aligned with pitch >= 4*width, multiple of 4");
 
+    if (o.mode != RC_MODE_REF && o.mode != RC_MODE_EXT) return rc_fail_arg("unknown mode");
+    if (o.mode == RC_MODE_EXT) {
+        if (!o.ext) return rc_fail_arg("mode EXT needs opts->ext");
+        if (o.ext->shininess_log2 < 0 || o.ext->shininess_log2 > 30) return rc_fail_arg("shininess_log2 must be 0..30");
+    }
+
     int kv;
     switch (o.variant) {
     case RC_VARIANT_AUTO:
@@ -191,6 +198,18 @@ extern "C" int rc_render(const rc_screen *screen, const rc_scene *scene, const r
     a.fx = scene->cam.forward.x;  a.fy = scene->cam.forward.y;  a.fz = scene->cam.forward.z;
     a.ux = scene->cam.up.x;       a.uy = scene->cam.up.y;       a.uz = scene->cam.up.z;
     a.rx = scene->cam.right.x;    a.ry = scene->cam.right.y;    a.rz = scene->cam.right.z;
+
+    if (o.mode == RC_MODE_EXT) {
+        const rc_ext &x = *o.ext;
+        a.ext_mode = 1;
+        a.has_plane = x.has_plane ? 1 : 0;
+        a.shadows = x.shadows ? 1 : 0;
+        a.shininess_log2 = x.shininess_log2;
+        a.pnx = x.plane_normal.x; a.pny = x.plane_normal.y; a.pnz = x.plane_normal.z; a.plane_h = x.plane_h;
+        a.pcx = x.plane_color.x; a.pcy = x.plane_color.y; a.pcz = x.plane_color.z;
+        a.lgx = x.light_pos.x; a.lgy = x.light_pos.y; a.lgz = x.light_pos.z;
+        a.specular = x.specular;
+    }
 
     {
         // range in which the tiled kernel's filter bounds are proven; outside it every lane

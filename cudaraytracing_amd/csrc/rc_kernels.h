@@ -33,6 +33,13 @@ struct RcKernArgs {
     float rx, ry, rz;        // cam.right
     float nF, nR, nU;        // upper bounds of |forward|, |right|, |up| (filter range check)
     int cam_ok;              // 0: camera basis outside the range the filter is proven for
+    // EXT mode (plane + point light + Phong + hard shadows; no counterpart in the reference)
+    int ext_mode;            // 0: the reference's shading; 1: EXT
+    int has_plane, shadows, shininess_log2;
+    float pnx, pny, pnz, plane_h;
+    float pcx, pcy, pcz;
+    float lgx, lgy, lgz;     // point light position
+    float specular;
     // filled in by the tiled launcher
     int lds_cap;             // spheres per LDS chunk (multiple of 16)
     int tiles_x, tiles_y;    // workgroup tiles covering the surface

@@ -56,16 +56,36 @@ __device__ __forceinline__ void rc_ray_dir(const RcKernArgs &a, float sx, float 
 // share the origin): v = o - pos, 2v (exact), 4c (exact scaling of c = v.v - r*r).
 struct RcExactSphere { float tvx, tvy, tvz, c4; };
 
-__device__ __forceinline__ RcExactSphere rc_exact_sphere(const RcKernArgs &a, int i)
+__device__ __forceinline__ RcExactSphere rc_exact_sphere_from(const RcKernArgs &a, int i,
+                                                             float ox, float oy, float oz)
 {
     float px = a.position[3 * i + 0], py = a.position[3 * i + 1], pz = a.position[3 * i + 2];
     float r = a.radius[i];
-    float vx = a.ox - px, vy = a.oy - py, vz = a.oz - pz;
+    float vx = ox - px, vy = oy - py, vz = oz - pz;
     float c = ((vx * vx + vy * vy) + vz * vz) - (r * r);
     RcExactSphere e;
     e.tvx = 2.0f * vx; e.tvy = 2.0f * vy; e.tvz = 2.0f * vz;
     e.c4 = 4.0f * c;
     return e;
+}
+
+__device__ __forceinline__ RcExactSphere rc_exact_sphere(const RcKernArgs &a, int i)
+{
+    return rc_exact_sphere_from(a, i, a.ox, a.oy, a.oz);
+}
+
+// kernel.cu:54,58-64: the distance findIntersection returns (-1 for a miss).
+__device__ __forceinline__ float rc_exact_dist(const RcExactSphere &e, float dx, float dy, float dz)
+{
+    float b = (e.tvx * dx + e.tvy * dy) + e.tvz * dz;
+    float disc = b * b - e.c4;
+    float dist = -1.0f;
+    if (disc >= 0.0f) {
+        float tmp = sqrtf(disc);
+        dist = ((-b - tmp) / 2.0f) - 0.000001f;
+        if (dist < 0.0f) dist = ((-b + tmp) / 2.0f) - 0.000001f;
+    }
+    return dist;
 }
 
 // kernel.cu:54,58-64 and the update at :91-94.
@@ -112,6 +132,92 @@ __device__ __forceinline__ void rc_shade(const RcKernArgs &a, int idx, float min
     b = a.color[3 * idx + 2] * c;
 }
 
+// ---------------------------------------------------------------------------------------
+// EXT mode: plane + one point light + Phong + hard shadows.  The reference has none of it;
+// the arithmetic below is this library's own definition, written with the reference's
+// building blocks (findIntersection, vec3::norm, vec3::reflect at vec3.h:163-166, the 1e-6
+// offset and the strict 0 < t < minDist rule), one rounding per operation.
+// ---------------------------------------------------------------------------------------
+constexpr int kPlaneIdx = -2;
+
+__device__ __forceinline__ float rc_dot3(float ax, float ay, float az, float bx, float by, float bz)
+{
+    return (ax * bx + ay * by) + az * bz;                   // vec3.h:153-156
+}
+
+// Plane n.x = h tested after the spheres: t = ((h - n.o) / (n.d)) - 1e-6f.
+__device__ __forceinline__ void rc_plane_test(const RcKernArgs &a, float dx, float dy, float dz,
+                                              float &minDist, int &idx)
+{
+    if (!a.has_plane) return;
+    float denom = rc_dot3(a.pnx, a.pny, a.pnz, dx, dy, dz);
+    if (denom != 0.0f) {
+        float t = ((a.plane_h - rc_dot3(a.pnx, a.pny, a.pnz, a.ox, a.oy, a.oz)) / denom) - 0.000001f;
+        if (t > 0.0f && t < minDist) { minDist = t; idx = kPlaneIdx; }
+    }
+}
+
+// Hit point, shadow-ray direction FROM the light, and the distance limit of the shadow test.
+__device__ __forceinline__ void rc_ext_ray(const RcKernArgs &a, float minDist, float dx, float dy, float dz,
+                                           float &ex, float &ey, float &ez, float &limit)
+{
+    float px = a.ox + dx * minDist, py = a.oy + dy * minDist, pz = a.oz + dz * minDist;
+    float lvx = a.lgx - px, lvy = a.lgy - py, lvz = a.lgz - pz;
+    float lightDist = sqrtf((lvx * lvx + lvy * lvy) + lvz * lvz);
+    float invL = 1.0f / lightDist;
+    ex = (px - a.lgx) * invL; ey = (py - a.lgy) * invL; ez = (pz - a.lgz) * invL;
+    limit = lightDist - 0.001f;
+}
+
+// Plane as an occluder of the shadow ray (not when the plane itself was hit).
+__device__ __forceinline__ bool rc_plane_shadow(const RcKernArgs &a, int idx, float ex, float ey, float ez, float limit)
+{
+    if (!a.has_plane || idx == kPlaneIdx) return false;
+    float de = rc_dot3(a.pnx, a.pny, a.pnz, ex, ey, ez);
+    if (de == 0.0f) return false;
+    float t = ((a.plane_h - rc_dot3(a.pnx, a.pny, a.pnz, a.lgx, a.lgy, a.lgz)) / de) - 0.000001f;
+    return t > 0.0f && t < limit;
+}
+
+__device__ __forceinline__ void rc_ext_shade(const RcKernArgs &a, int idx, float minDist,
+                                             float dx, float dy, float dz, bool shadowed,
+                                             float &r, float &g, float &b)
+{
+    float px = a.ox + dx * minDist, py = a.oy + dy * minDist, pz = a.oz + dz * minDist;
+    float nx, ny, nz, cr, cg, cb;
+    if (idx >= 0) {
+        nx = px - a.position[3 * idx + 0]; ny = py - a.position[3 * idx + 1]; nz = pz - a.position[3 * idx + 2];
+        float inv = 1.0f / sqrtf((nx * nx + ny * ny) + nz * nz);
+        nx = nx * inv; ny = ny * inv; nz = nz * inv;
+        cr = a.color[3 * idx + 0]; cg = a.color[3 * idx + 1]; cb = a.color[3 * idx + 2];
+    } else {
+        float inv = 1.0f / sqrtf((a.pnx * a.pnx + a.pny * a.pny) + a.pnz * a.pnz);
+        nx = a.pnx * inv; ny = a.pny * inv; nz = a.pnz * inv;
+        if (rc_dot3(a.pnx, a.pny, a.pnz, dx, dy, dz) > 0.0f) { nx = nx * -1.0f; ny = ny * -1.0f; nz = nz * -1.0f; }
+        cr = a.pcx; cg = a.pcy; cb = a.pcz;
+    }
+    float c = 0.2f, spec = 0.0f;
+    if (!shadowed) {
+        float lvx = a.lgx - px, lvy = a.lgy - py, lvz = a.lgz - pz;
+        float invL = 1.0f / sqrtf((lvx * lvx + lvy * lvy) + lvz * lvz);
+        float ldx = lvx * invL, ldy = lvy * invL, ldz = lvz * invL;
+        float diff = fmaxf(rc_dot3(nx, ny, nz, ldx, ldy, ldz), 0.0f);
+        c = c + diff * 0.5f;
+        // Ldir.reflect(N): N * Ldir.dot(N) / N.length() / N.length() * 2 - Ldir  (vec3.h:163-166)
+        float dn = rc_dot3(ldx, ldy, ldz, nx, ny, nz);
+        float tx = nx * dn, ty = ny * dn, tz = nz * dn;
+        float il = 1.0f / sqrtf((nx * nx + ny * ny) + nz * nz);
+        tx = tx * il; ty = ty * il; tz = tz * il;
+        tx = tx * il; ty = ty * il; tz = tz * il;
+        tx = tx * 2.0f; ty = ty * 2.0f; tz = tz * 2.0f;
+        float rx = tx - ldx, ry = ty - ldy, rz = tz - ldz;
+        float s = fmaxf(rc_dot3(rx, ry, rz, dx * -1.0f, dy * -1.0f, dz * -1.0f), 0.0f);
+        for (int k = 0; k < a.shininess_log2; k++) s = s * s;
+        spec = a.specular * s;
+    }
+    r = cr * c + spec; g = cg * c + spec; b = cb * c + spec;
+}
+
 // D3D float -> UNORM8: NaN -> 0, clamp [0,1], *255, +0.5, truncate (DXManager.cpp:134,328).
 __device__ __forceinline__ unsigned rc_unorm8(float f)
 {
@@ -139,6 +245,7 @@ __device__ __forceinline__ void rc_store_pixel(const RcKernArgs &a, int x, int r
 // ---------------------------------------------------------------------------------------
 } // namespace
 
+template <bool EXT>
 __global__ __launch_bounds__(256) void rc_draw_literal(RcKernArgs a)
 {
     int x = blockIdx.x * 64 + (threadIdx.x & 63);
@@ -155,7 +262,26 @@ __global__ __launch_bounds__(256) void rc_draw_literal(RcKernArgs a)
         rc_exact_test(e, dx, dy, dz, i, minDist, idx);
     }
     float r = 0.0f, g = 0.0f, b = 0.0f;
-    if (idx >= 0) rc_shade(a, idx, minDist, dx, dy, dz, r, g, b);
+    if (EXT) {
+        rc_plane_test(a, dx, dy, dz, minDist, idx);
+        if (idx != -1) {
+            bool shadowed = false;
+            if (a.shadows) {
+                float ex, ey, ez, limit;
+                rc_ext_ray(a, minDist, dx, dy, dz, ex, ey, ez, limit);
+                for (int i = 0; i < a.n; i++) {
+                    if (i == idx) continue;
+                    RcExactSphere e = rc_exact_sphere_from(a, i, a.lgx, a.lgy, a.lgz);
+                    float dist = rc_exact_dist(e, ex, ey, ez);
+                    if (dist > 0.0f && dist < limit) shadowed = true;
+                }
+                if (rc_plane_shadow(a, idx, ex, ey, ez, limit)) shadowed = true;
+            }
+            rc_ext_shade(a, idx, minDist, dx, dy, dz, shadowed, r, g, b);
+        }
+    } else if (idx >= 0) {
+        rc_shade(a, idx, minDist, dx, dy, dz, r, g, b);
+    }
     rc_store_pixel(a, x, row, r, g, b);
 }
 
@@ -234,7 +360,139 @@ constexpr int kGroupsPerBlock = kBlockSpheres / kGroup;
 //   int    has_always
 __host__ __device__ constexpr size_t rc_lds_bytes(int cap) { return (size_t)cap * 12 + (size_t)cap + 16; }
 
+// Shadow-ray filter record of one sphere for rays that all start at the light:
+// h = -(light - pos) * k with the same k as above (c taken from the light).  A shadow ray
+// with unit direction e can meet the sphere in front of the light only if h.e >= 1 up to
+// rounding: the exact test needs -(v.e) >= sqrt(c)(1-u) - 3.01uL, the fma chain differs from
+// k(-(v.e)) by <= 7.1ukL, and 1/k = sqrt(c)(1 - 2^-19) - 2^-17 L leaves > 10x that margin.
+struct RcLightRecord { float hx, hy, hz; bool always; };
+
+__device__ __forceinline__ RcLightRecord rc_prepass_light(const RcKernArgs &a, int i)
+{
+    float px = a.position[3 * i + 0], py = a.position[3 * i + 1], pz = a.position[3 * i + 2];
+    float r = a.radius[i];
+    float vx = a.lgx - px, vy = a.lgy - py, vz = a.lgz - pz;
+    float vv = (vx * vx + vy * vy) + vz * vz;
+    float c = vv - r * r;
+    float thr = sqrtf(c) * (1.0f - 0x1p-19f) - 0x1p-17f * sqrtf(vv);
+    RcLightRecord rec;
+    rec.always = !(c > 0.0f) || !(thr > 0.0f) || !(vv < 0x1p80f) || !(vv > 0x1p-80f);
+    float k = 1.0f / thr;
+    rec.hx = -k * vx; rec.hy = -k * vy; rec.hz = -k * vz;
+    rec.always = rec.always || !(fabsf(rec.hx) < 0x1p40f) || !(fabsf(rec.hy) < 0x1p40f) || !(fabsf(rec.hz) < 0x1p40f);
+    if (rec.always) { rec.hx = 0.0f; rec.hy = 0.0f; rec.hz = 0.0f; }
+    return rec;
+}
+
+// Hard-shadow pass of EXT mode: for every hit pixel, is any sphere other than the one hit
+// between the light and the point?  Same structure as the primary search (LDS records,
+// conservative FMA filter, exact re-test of what the filter cannot rule out); the rays share
+// the light as origin but their directions are arbitrary, so the filter is the 3-FMA dot
+// product h.e >= 1 instead of the separable form.
 template <int P>
+__device__ __forceinline__ void rc_shadow_pass(const RcKernArgs &a, char *lds,
+                                               const float (&ex)[P], const float (&ey)[P], const float (&ez)[P],
+                                               const float (&limit)[P], const int (&idx)[P], bool (&shadowed)[P])
+{
+    const int cap = a.lds_cap;
+    float4 *s_rec = reinterpret_cast<float4 *>(lds);
+    unsigned *s_flag = reinterpret_cast<unsigned *>(lds + (size_t)cap * 12);
+    int *s_has_always = reinterpret_cast<int *>(lds + (size_t)cap * 13);
+    const int tid = threadIdx.x;
+
+    bool lane_forced = false;
+#pragma unroll
+    for (int p = 0; p < P; p++) {
+        const float ee = (ex[p] * ex[p] + ey[p] * ey[p]) + ez[p] * ez[p];
+        // hit pixels whose shadow ray is not a unit vector (point at the light, overflow) bypass the filter
+        if (idx[p] != -1 && (!(ee < 1.0f + 0x1p-19f) || !(ee > 1.0f - 0x1p-19f))) lane_forced = true;
+    }
+    const unsigned long long forced_mask = __builtin_amdgcn_ballot_w64(lane_forced);
+
+    for (int base = 0; base < a.n; base += cap) {
+        const int cn = min(a.n - base, cap);
+        const int cnb = (cn + kBlockSpheres - 1) & ~(kBlockSpheres - 1);
+        __syncthreads();                           // primary records / previous chunk consumed
+        if (tid == 0) *s_has_always = 0;
+        __syncthreads();
+        {
+            float *rec = reinterpret_cast<float *>(s_rec);
+            unsigned char *flagb = reinterpret_cast<unsigned char *>(s_flag);
+            for (int j = tid; j < cnb; j += kBlock) {
+                RcLightRecord r;
+                r.hx = 0.0f; r.hy = 0.0f; r.hz = 0.0f; r.always = false;
+                if (j < cn) r = rc_prepass_light(a, base + j);
+                float *g = rec + (j >> 2) * 12 + (j & 3);
+                g[0] = r.hx; g[4] = r.hy; g[8] = r.hz;
+                flagb[j] = r.always ? 1 : 0;
+                if (r.always) *s_has_always = 1;
+            }
+        }
+        __syncthreads();
+        const unsigned long long flag0_mask = (*s_has_always != 0) ? ~0ull : forced_mask;
+        const int nblocks = cnb / kBlockSpheres;
+
+        for (int blk = 0; blk < nblocks; blk++) {
+            float m[P];
+#pragma unroll
+            for (int p = 0; p < P; p++) m[p] = 0.0f;
+#pragma unroll
+            for (int g = 0; g < kGroupsPerBlock; g++) {
+                const float4 HX = s_rec[(blk * kGroupsPerBlock + g) * 3 + 0];
+                const float4 HY = s_rec[(blk * kGroupsPerBlock + g) * 3 + 1];
+                const float4 HZ = s_rec[(blk * kGroupsPerBlock + g) * 3 + 2];
+#pragma unroll
+                for (int p = 0; p < P; p++) {
+                    const rc_f2 e0 = {ex[p], ex[p]}, e1 = {ey[p], ey[p]}, e2 = {ez[p], ez[p]};
+                    const rc_f2 f01 = rc_fma2(e2, rc_f2{HZ.x, HZ.y}, rc_fma2(e1, rc_f2{HY.x, HY.y}, e0 * rc_f2{HX.x, HX.y}));
+                    const rc_f2 f23 = rc_fma2(e2, rc_f2{HZ.z, HZ.w}, rc_fma2(e1, rc_f2{HY.z, HY.w}, e0 * rc_f2{HX.z, HX.w}));
+                    m[p] = fmaxf(fmaxf(m[p], f01.x), f01.y);
+                    m[p] = fmaxf(fmaxf(m[p], f23.x), f23.y);
+                }
+            }
+            unsigned long long flagged = flag0_mask;
+#pragma unroll
+            for (int p = 0; p < P; p++) flagged |= __builtin_amdgcn_ballot_w64(m[p] >= 1.0f);
+            if (flagged != 0ull) {
+#pragma nounroll
+                for (int g = 0; g < kGroupsPerBlock; g++) {
+                    const int gi = blk * kGroupsPerBlock + g;
+                    if (gi * kGroup >= cn) break;
+                    const float4 HX = s_rec[gi * 3 + 0];
+                    const float4 HY = s_rec[gi * 3 + 1];
+                    const float4 HZ = s_rec[gi * 3 + 2];
+                    const unsigned fl = __builtin_amdgcn_readfirstlane(s_flag[gi]);
+                    unsigned long long cm[kGroup];
+#pragma unroll
+                    for (int s = 0; s < kGroup; s++) cm[s] = ((fl >> (8 * s)) & 0xffu) ? ~0ull : forced_mask;
+#pragma unroll
+                    for (int p = 0; p < P; p++) {
+                        const rc_f2 e0 = {ex[p], ex[p]}, e1 = {ey[p], ey[p]}, e2 = {ez[p], ez[p]};
+                        const rc_f2 f01 = rc_fma2(e2, rc_f2{HZ.x, HZ.y}, rc_fma2(e1, rc_f2{HY.x, HY.y}, e0 * rc_f2{HX.x, HX.y}));
+                        const rc_f2 f23 = rc_fma2(e2, rc_f2{HZ.z, HZ.w}, rc_fma2(e1, rc_f2{HY.z, HY.w}, e0 * rc_f2{HX.z, HX.w}));
+                        cm[0] |= __builtin_amdgcn_ballot_w64(f01.x >= 1.0f);
+                        cm[1] |= __builtin_amdgcn_ballot_w64(f01.y >= 1.0f);
+                        cm[2] |= __builtin_amdgcn_ballot_w64(f23.x >= 1.0f);
+                        cm[3] |= __builtin_amdgcn_ballot_w64(f23.y >= 1.0f);
+                    }
+#pragma unroll
+                    for (int s = 0; s < kGroup; s++) {
+                        const int j = gi * kGroup + s;
+                        if (cm[s] == 0ull || j >= cn) continue;
+                        const RcExactSphere e = rc_exact_sphere_from(a, base + j, a.lgx, a.lgy, a.lgz);
+#pragma unroll
+                        for (int p = 0; p < P; p++) {
+                            const float dist = rc_exact_dist(e, ex[p], ey[p], ez[p]);
+                            if (base + j != idx[p] && dist > 0.0f && dist < limit[p]) shadowed[p] = true;
+                        }
+                    }
+                }
+            }
+        }
+    }
+}
+
+template <int P, bool EXT>
 __device__ __forceinline__ void rc_tiled_body(const RcKernArgs &a, char *lds)
 {
     constexpr int TW = 8 * P;   // wave tile width in pixels
@@ -374,13 +632,37 @@ __device__ __forceinline__ void rc_tiled_body(const RcKernArgs &a, char *lds)
             }
         }
 
+        bool shadowed[P];
+#pragma unroll
+        for (int p = 0; p < P; p++) shadowed[p] = false;
+        if (EXT) {
+#pragma unroll
+            for (int p = 0; p < P; p++) rc_plane_test(a, dx[p], dy[p], dz[p], minDist[p], idx[p]);
+            if (a.shadows) {
+                float ex[P], ey[P], ez[P], limit[P];
+#pragma unroll
+                for (int p = 0; p < P; p++) {
+                    ex[p] = 0.0f; ey[p] = 0.0f; ez[p] = 0.0f; limit[p] = -1.0f;   // misses cast no shadow ray
+                    if (idx[p] != -1) rc_ext_ray(a, minDist[p], dx[p], dy[p], dz[p], ex[p], ey[p], ez[p], limit[p]);
+                }
+                rc_shadow_pass<P>(a, lds, ex, ey, ez, limit, idx, shadowed);
+#pragma unroll
+                for (int p = 0; p < P; p++)
+                    if (idx[p] != -1 && rc_plane_shadow(a, idx[p], ex[p], ey[p], ez[p], limit[p])) shadowed[p] = true;
+            }
+        }
+
         if (row < a.rows) {
 #pragma unroll
             for (int p = 0; p < P; p++) {
                 const int x = x0 + 8 * p;
                 if (x < a.width) {
                     float r = 0.0f, g = 0.0f, b = 0.0f;
-                    if (idx[p] >= 0) rc_shade(a, idx[p], minDist[p], dx[p], dy[p], dz[p], r, g, b);
+                    if (EXT) {
+                        if (idx[p] != -1) rc_ext_shade(a, idx[p], minDist[p], dx[p], dy[p], dz[p], shadowed[p], r, g, b);
+                    } else if (idx[p] >= 0) {
+                        rc_shade(a, idx[p], minDist[p], dx[p], dy[p], dz[p], r, g, b);
+                    }
                     rc_store_pixel(a, x, row, r, g, b);
                 }
             }
@@ -390,11 +672,11 @@ __device__ __forceinline__ void rc_tiled_body(const RcKernArgs &a, char *lds)
 
 } // namespace
 
-template <int P>
+template <int P, bool EXT>
 __global__ __launch_bounds__(256) void rc_draw_tiled(RcKernArgs a)
 {
     extern __shared__ __attribute__((aligned(16))) char rc_lds[];
-    rc_tiled_body<P>(a, rc_lds);
+    rc_tiled_body<P, EXT>(a, rc_lds);
 }
 
 // float RGBA -> RGBA8 (the display step that follows the path in the reference)
@@ -429,7 +711,14 @@ static hipError_t rc_launch_tiled(RcKernArgs a, hipStream_t stream)
     a.tiles_x = (a.width + 16 * P - 1) / (16 * P);
     a.tiles_y = (a.rows + 15) / 16;
     const unsigned grid = (unsigned)rc_tile_count<P>(a);
-    hipLaunchKernelGGL(rc_draw_tiled<P>, dim3(grid), dim3(256), rc_lds_bytes(a.lds_cap), stream, a);
+    if (a.ext_mode) {
+        if constexpr (P <= 4)
+            hipLaunchKernelGGL((rc_draw_tiled<P, true>), dim3(grid), dim3(256), rc_lds_bytes(a.lds_cap), stream, a);
+        else
+            return hipErrorInvalidValue;           // EXT is built for <= 4 pixels per lane
+    } else {
+        hipLaunchKernelGGL((rc_draw_tiled<P, false>), dim3(grid), dim3(256), rc_lds_bytes(a.lds_cap), stream, a);
+    }
     return hipGetLastError();
 }
 
@@ -438,17 +727,19 @@ hipError_t rc_launch_draw(const RcKernArgs &a, int variant, int compute_units, h
     if (compute_units <= 0) compute_units = 256;
     if (variant == RC_KVARIANT_LITERAL) {
         dim3 grid((a.width + 63) / 64, (a.rows + 3) / 4);
-        hipLaunchKernelGGL(rc_draw_literal, grid, dim3(256), 0, stream, a);
+        if (a.ext_mode) hipLaunchKernelGGL(rc_draw_literal<true>, grid, dim3(256), 0, stream, a);
+        else hipLaunchKernelGGL(rc_draw_literal<false>, grid, dim3(256), 0, stream, a);
         return hipGetLastError();
     }
     if (variant == RC_KVARIANT_TILED2) return rc_launch_tiled<2>(a, stream);
     if (variant == RC_KVARIANT_TILED4) return rc_launch_tiled<4>(a, stream);
-    if (variant == RC_KVARIANT_TILED8) return rc_launch_tiled<8>(a, stream);
+    if (variant == RC_KVARIANT_TILED8) return a.ext_mode ? rc_launch_tiled<4>(a, stream) : rc_launch_tiled<8>(a, stream);
     // Automatic: more pixels per lane share more of the per-sphere work, but the frame must
     // still cut into enough workgroups to fill the chip (>= 5 per CU; measured crossovers:
     // 1280x768 -> 2, 1920x1080 -> 4, 3840x2160 and up -> 8 pixels per lane).
     const long long want = 5LL * compute_units;
-    if (rc_tile_count<8>(a) >= want) return rc_launch_tiled<8>(a, stream);
+    // EXT keeps shadow-ray state per pixel: at most 4 pixels per lane
+    if (!a.ext_mode && rc_tile_count<8>(a) >= want) return rc_launch_tiled<8>(a, stream);
     if (rc_tile_count<4>(a) >= want) return rc_launch_tiled<4>(a, stream);
     return rc_launch_tiled<2>(a, stream);
 }

@@ -69,17 +69,46 @@ enum {
     RC_VARIANT_TILED = 2     /* LDS-staged scene, FMA filter + exact re-test (default)     */
 };
 
+/* Shading modes. */
+enum {
+    RC_MODE_REF = 0,   /* the reference's math: spheres, ambient + three directional Lambert
+                          lights (kernel.cu:21-42).  Parity is graded on this mode.          */
+    RC_MODE_EXT = 1    /* + one plane, one point light, Phong, hard shadows.  The reference
+                          has no such code: this mode is defined by this library (and its
+                          CPU oracle) and is NOT pinned by the reference.                    */
+};
+
+/* EXT-mode scene additions (no counterpart in the reference; 56 bytes).
+ *   primary search  spheres as in REF, then the plane n.x = h last:
+ *                   t = ((h - n.o) / (n.d)) - 1e-6f, accepted if n.d != 0 and 0 < t < minDist
+ *   shadow          ray from the light to the hit point; shadowed if a sphere other than the
+ *                   one hit (or the plane, unless the plane was hit) lies closer than
+ *                   |light - point| - 0.001
+ *   colour          base * (0.2 + 0.5 max(N.L, 0)) + specular * max(R.V, 0)^(2^shininess_log2),
+ *                   R = L.reflect(N) as vec3.h:163-166; ambient only when shadowed        */
+typedef struct rc_ext {
+    rc_vec3 plane_normal;   /* need not be a unit vector */
+    float plane_h;
+    rc_vec3 plane_color;
+    rc_vec3 light_pos;
+    float specular;
+    int shininess_log2;     /* 0..30 */
+    int has_plane;
+    int shadows;
+} rc_ext;
+
 /* What the reference launch lacks (kernel.cu:114-131 has no options). Zero-initialise. */
 typedef struct rc_opts {
     int y_offset;        /* frame row stored in surface row 0 (row-band rendering)        */
     int full_height;     /* frame height used in the y angle (kernel.cu:47); 0 = height   */
     int variant;         /* RC_VARIANT_*                                                   */
-    int reserved0;
+    int mode;            /* RC_MODE_*                                                      */
     void *stream;        /* hipStream_t; NULL = the default stream as at kernel.cu:123     */
     void *rgba8;         /* optional DEVICE R8G8B8A8 surface written with the same frame   */
     size_t rgba8_pitch;  /* bytes per rgba8 row (>= 4*width)                               */
     int rgba8_flip;      /* != 0: surface row 0 goes to the LAST rgba8 row (top-down image)*/
     int reserved1;
+    const rc_ext *ext;   /* HOST pointer, required when mode == RC_MODE_EXT                */
 } rc_opts;
 
 /* ---- the hot path ---------------------------------------------------------------------- */

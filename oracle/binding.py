@@ -34,6 +34,13 @@ class Screen(C.Structure):
     _fields_ = [("surface", C.c_void_p), ("width", C.c_int), ("height", C.c_int), ("pitch", C.c_size_t)]
 
 
+class Ext(C.Structure):
+    """EXT-mode parameters (plane, point light, Phong, shadows); layout of rco_ext / rc_ext."""
+    _fields_ = [("plane_normal", Vec3), ("plane_h", C.c_float), ("plane_color", Vec3),
+                ("light_pos", Vec3), ("specular", C.c_float), ("shininess_log2", C.c_int),
+                ("has_plane", C.c_int), ("shadows", C.c_int)]
+
+
 _lib = None
 
 
@@ -50,6 +57,8 @@ def load():
     lib = C.CDLL(LIB_PATH)
     lib.rco_render_rows.argtypes = [C.POINTER(Screen), C.POINTER(Scene), C.c_int, C.c_int, C.c_int, C.c_int, C.c_int]
     lib.rco_render_rows.restype = None
+    lib.rco_render_rows_ext.argtypes = [C.POINTER(Screen), C.POINTER(Scene), C.POINTER(Ext), C.c_int, C.c_int, C.c_int, C.c_int, C.c_int]
+    lib.rco_render_rows_ext.restype = None
     lib.rco_camera_data.argtypes = [Vec3, Vec3, C.c_int, C.c_int]
     lib.rco_camera_data.restype = Camera
     lib.rco_generate_scene.argtypes = [C.c_uint32, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p]
@@ -107,8 +116,14 @@ def screen_over(array, width, height):
     return s
 
 
-def render(pos, rad, col, cam, width, height, y_offset=0, full_height=None, threads=None, fill=None):
-    """Reference-exact frame (or row band) on the CPU -> float32 [height, width, 4]."""
+def default_ext(has_plane=1, shadows=1):
+    """The EXT scene used by the benchmark configurations: floor plane y = -6, one point light."""
+    return Ext(Vec3(0.0, 1.0, 0.0), -6.0, Vec3(0.6, 0.6, 0.55), Vec3(8.0, 14.0, 12.0), 0.4, 5, has_plane, shadows)
+
+
+def render(pos, rad, col, cam, width, height, y_offset=0, full_height=None, threads=None, fill=None, ext=None):
+    """Reference-exact frame (or row band) on the CPU -> float32 [height, width, 4].
+    With `ext` (an Ext struct) the frame is rendered in EXT mode instead."""
     lib = load()
     full_height = height if full_height is None else full_height
     threads = threads or min(os.cpu_count() or 1, 16)
@@ -117,7 +132,10 @@ def render(pos, rad, col, cam, width, height, y_offset=0, full_height=None, thre
         out.view(np.uint8)[...] = fill
     scene, keep = make_scene(pos, rad, col, cam)
     screen = screen_over(out.reshape(height, width * 4), width, height)
-    lib.rco_render_rows(C.byref(screen), C.byref(scene), y_offset, full_height, 0, height, threads)
+    if ext is not None:
+        lib.rco_render_rows_ext(C.byref(screen), C.byref(scene), C.byref(ext), y_offset, full_height, 0, height, threads)
+    else:
+        lib.rco_render_rows(C.byref(screen), C.byref(scene), y_offset, full_height, 0, height, threads)
     del keep
     return out
 

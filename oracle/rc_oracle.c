@@ -136,10 +136,103 @@ int rco_draw_pixel(const rco_screen *screen, const rco_scene *scene, int x, int 
     return idx;
 }
 
+/* ---- EXT mode (definition in rc_oracle.h; unpinned by the reference) ------------------ */
+
+/* vec3.h:163-166: u * this.dot(u) / u.length() / u.length() * 2 - this, left to right;
+ * operator/(float t) multiplies by (1 / t) (vec3.h:131-134) */
+static inline rco_vec3 v_reflect(rco_vec3 self, rco_vec3 u)
+{
+    rco_vec3 t = v_scale(u, v_dot(self, u));
+    t = v_scale(t, 1.0f / v_length(u));
+    t = v_scale(t, 1.0f / v_length(u));
+    t = v_scale(t, 2.0f);
+    return v_sub(t, self);
+}
+
+int rco_draw_pixel_ext(const rco_screen *screen, const rco_scene *scene, const rco_ext *ext,
+                       int x, int y, int y_offset, int full_height)
+{
+    int row = y - y_offset;
+    if (x >= screen->width || row >= screen->height || row < 0 || x < 0) return -1;
+    float *pixel = (float *)((char *)screen->surface + (size_t)row * screen->pitch) + 4 * x;
+
+    rco_vec3 d = rco_cast_screen_ray(&scene->cam, x, y, screen->width, full_height);
+    rco_vec3 o = scene->cam.position;
+    pixel[3] = 1.0f;
+
+    float minDist = 10000.0f;
+    int idx = -1;
+    for (int i = 0; i < scene->sphere_num; i++) {
+        float dist = rco_find_intersection(scene->position[i], scene->radius[i], o, d);
+        if (dist > 0.0f && dist < minDist) { minDist = dist; idx = i; }
+    }
+    float denom = 0.0f;
+    if (ext->has_plane) {
+        denom = v_dot(ext->plane_normal, d);
+        if (denom != 0.0f) {
+            float t = ((ext->plane_h - v_dot(ext->plane_normal, o)) / denom) - 0.000001f;
+            if (t > 0.0f && t < minDist) { minDist = t; idx = -2; }
+        }
+    }
+    if (idx == -1) {
+        pixel[0] = 0.0f; pixel[1] = 0.0f; pixel[2] = 0.0f;
+        return idx;
+    }
+
+    rco_vec3 P = v_add(o, v_scale(d, minDist));
+    rco_vec3 N, base;
+    if (idx >= 0) {
+        N = rco_norm(v_sub(P, scene->position[idx]));
+        base = scene->color[idx];
+    } else {
+        N = rco_norm(ext->plane_normal);
+        if (denom > 0.0f) N = v_scale(N, -1.0f);
+        base = ext->plane_color;
+    }
+    rco_vec3 Lv = v_sub(ext->light_pos, P);
+    float lightDist = v_length(Lv);
+    float invL = 1.0f / lightDist;
+    rco_vec3 Ldir = v_scale(Lv, invL);
+
+    int shadowed = 0;
+    if (ext->shadows) {
+        rco_vec3 e = v_scale(v_sub(P, ext->light_pos), invL);
+        float limit = lightDist - 0.001f;
+        for (int i = 0; i < scene->sphere_num; i++) {
+            if (i == idx) continue;
+            float dist = rco_find_intersection(scene->position[i], scene->radius[i], ext->light_pos, e);
+            if (dist > 0.0f && dist < limit) shadowed = 1;
+        }
+        if (ext->has_plane && idx != -2) {
+            float de = v_dot(ext->plane_normal, e);
+            if (de != 0.0f) {
+                float t = ((ext->plane_h - v_dot(ext->plane_normal, ext->light_pos)) / de) - 0.000001f;
+                if (t > 0.0f && t < limit) shadowed = 1;
+            }
+        }
+    }
+
+    float c = 0.2f;
+    float spec = 0.0f;
+    if (!shadowed) {
+        float diff = fmaxf(v_dot(N, Ldir), 0.0f);
+        c = c + (float)((double)diff * 0.5);
+        rco_vec3 R = v_reflect(Ldir, N);
+        float s = fmaxf(v_dot(R, v_scale(d, -1.0f)), 0.0f);
+        for (int k = 0; k < ext->shininess_log2; k++) s = s * s;
+        spec = ext->specular * s;
+    }
+    pixel[0] = base.x * c + spec;
+    pixel[1] = base.y * c + spec;
+    pixel[2] = base.z * c + spec;
+    return idx;
+}
+
 /* ---- row-split driver (the reference's grid, kernel.cu:120-123, minus the floor) ----- */
 typedef struct {
     const rco_screen *screen;
     const rco_scene *scene;
+    const rco_ext *ext;          /* NULL: REF mode */
     int y_offset, full_height, row_begin, row_end;
     int tid, threads;
 } rco_job;
@@ -149,20 +242,24 @@ static void *rco_worker(void *arg)
     rco_job *j = (rco_job *)arg;
     /* interleaved rows: near-equal load whatever the hit distribution */
     for (int row = j->row_begin + j->tid; row < j->row_end; row += j->threads)
-        for (int x = 0; x < j->screen->width; x++)
-            rco_draw_pixel(j->screen, j->scene, x, row + j->y_offset, j->y_offset, j->full_height);
+        for (int x = 0; x < j->screen->width; x++) {
+            if (j->ext)
+                rco_draw_pixel_ext(j->screen, j->scene, j->ext, x, row + j->y_offset, j->y_offset, j->full_height);
+            else
+                rco_draw_pixel(j->screen, j->scene, x, row + j->y_offset, j->y_offset, j->full_height);
+        }
     return NULL;
 }
 
-void rco_render_rows(const rco_screen *screen, const rco_scene *scene, int y_offset,
-                     int full_height, int row_begin, int row_end, int threads)
+void rco_render_rows_ext(const rco_screen *screen, const rco_scene *scene, const rco_ext *ext,
+                         int y_offset, int full_height, int row_begin, int row_end, int threads)
 {
     if (threads < 1) threads = 1;
     if (threads > 1024) threads = 1024;
     rco_job *jobs = (rco_job *)calloc((size_t)threads, sizeof(rco_job));
     pthread_t *tids = (pthread_t *)calloc((size_t)threads, sizeof(pthread_t));
     for (int t = 0; t < threads; t++) {
-        rco_job j = {screen, scene, y_offset, full_height, row_begin, row_end, t, threads};
+        rco_job j = {screen, scene, ext, y_offset, full_height, row_begin, row_end, t, threads};
         jobs[t] = j;
     }
     for (int t = 1; t < threads; t++) pthread_create(&tids[t], NULL, rco_worker, &jobs[t]);
@@ -170,6 +267,12 @@ void rco_render_rows(const rco_screen *screen, const rco_scene *scene, int y_off
     for (int t = 1; t < threads; t++) pthread_join(tids[t], NULL);
     free(jobs);
     free(tids);
+}
+
+void rco_render_rows(const rco_screen *screen, const rco_scene *scene, int y_offset,
+                     int full_height, int row_begin, int row_end, int threads)
+{
+    rco_render_rows_ext(screen, scene, NULL, y_offset, full_height, row_begin, row_end, threads);
 }
 
 void rco_render(const rco_screen *screen, const rco_scene *scene, int threads)

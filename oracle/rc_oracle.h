@@ -109,6 +109,44 @@ uint64_t rco_fnv1a64_words(const rco_screen *screen, uint64_t basis);
 void rco_hit_mask(const rco_screen *screen, const rco_scene *scene, int y_offset,
                   int full_height, uint8_t *mask_bits, int32_t *index_out);
 
+/* ---- EXT mode: plane + one point light + Phong + hard shadows ---------------------------
+ * The reference has NONE of this (spheres, three directional Lambert lights, no shadows:
+ * kernel.cu:21-42,52-67), so there is nothing to pin it to: EXT parity is UNPINNED BY THE
+ * REFERENCE.  This restatement DEFINES the mode, in the reference's own vocabulary
+ * (findIntersection, vec3::norm, vec3::reflect at vec3.h:163-166, the 1e-6 offset and the
+ * strict 0 < t < minDist rule of kernel.cu:61,91), and the HIP path is held to it bit for bit.
+ *
+ *   primary search  spheres exactly as REF, then the plane n.x = h LAST:
+ *                   t = ((h - n.o) / (n.d)) - 1e-6f, accepted if n.d != 0 and 0 < t < minDist
+ *   hit point       P = o + d * minDist                                   (kernel.cu:99)
+ *   normal          sphere: (P - pos).norm();  plane: n.norm(), negated when n.d > 0
+ *   light           Lv = light - P, lightDist = Lv.length(), Ldir = Lv * (1 / lightDist)
+ *   shadow (if on)  ray from the LIGHT: e = (P - light) * (1 / lightDist); the point is shadowed
+ *                   if for some sphere i != hit sphere: dist = findIntersection(pos_i, r_i, light, e)
+ *                   has 0 < dist < lightDist - 0.001f; or (hit is not the plane, plane on) the plane
+ *                   has n.e != 0 and 0 < ((h - n.light) / (n.e)) - 1e-6f < lightDist - 0.001f
+ *   colour          c = 0.2; if not shadowed: c += (float)(fmaxf(N.Ldir, 0) * 0.5) and
+ *                   s = fmaxf(Ldir.reflect(N) . (-d), 0), squared `shininess_log2` times,
+ *                   spec = specular * s;  rgb = base * c + spec;  alpha = 1
+ */
+typedef struct {
+    rco_vec3 plane_normal;
+    float plane_h;
+    rco_vec3 plane_color;
+    rco_vec3 light_pos;
+    float specular;
+    int shininess_log2;
+    int has_plane;
+    int shadows;
+} rco_ext;
+
+/* returns the winning sphere index, -2 for the plane, -1 for a miss */
+int rco_draw_pixel_ext(const rco_screen *screen, const rco_scene *scene, const rco_ext *ext,
+                       int x, int y, int y_offset, int full_height);
+
+void rco_render_rows_ext(const rco_screen *screen, const rco_scene *scene, const rco_ext *ext,
+                         int y_offset, int full_height, int row_begin, int row_end, int threads);
+
 #ifdef __cplusplus
 }
 #endif

@@ -37,8 +37,15 @@ class GpuScene:
             b.free()
 
 
+def to_rc_ext(ext):
+    """oracle Ext struct -> ABI RcExt (identical 56-byte layout)."""
+    out = abi.RcExt()
+    C.memmove(C.addressof(out), C.addressof(ext), C.sizeof(out))
+    return out
+
+
 def gpu_render(pos, rad, col, cam, width, height, variant=abi.VARIANT_AUTO, y_offset=0, full_height=0,
-               pitch=None, want_rgba8=False, flip=False, fill=1, scene=None):
+               pitch=None, want_rgba8=False, flip=False, fill=1, scene=None, ext=None):
     """Render through rc_render -> float32 [height, pitch/4] raw rows (and RGBA8 if asked)."""
     lib = abi.load()
     own = scene is None
@@ -48,6 +55,10 @@ def gpu_render(pos, rad, col, cam, width, height, variant=abi.VARIANT_AUTO, y_of
     abi.check(lib.rc_memset(surf.ptr, fill, pitch * height, None), "rc_memset")
     screen = abi.RcScreen(surf.ptr.value, width, height, pitch)
     opts = abi.RcOpts(y_offset=y_offset, full_height=full_height, variant=variant)
+    if ext is not None:
+        rc_ext = ext if isinstance(ext, abi.RcExt) else to_rc_ext(ext)
+        opts.mode = abi.MODE_EXT
+        opts.ext = C.pointer(rc_ext)
     rgba = None
     if want_rgba8:
         rgba = DeviceBuffer(width * 4 * height)

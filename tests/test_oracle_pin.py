@@ -75,14 +75,48 @@ def test_golden_samples_all_frames(oracle, golden):
         scene, keep = oracle.make_scene(pos, rad, col, cam)
         w, h = fx["width"], fx["height"]
         row = np.zeros((1, w * 4), np.float32)
+        lib.rco_draw_pixel.argtypes = [C.POINTER(oracle.Screen), C.POINTER(oracle.Scene), C.c_int, C.c_int, C.c_int, C.c_int]
+        lib.rco_draw_pixel_ext.argtypes = [C.POINTER(oracle.Screen), C.POINTER(oracle.Scene), C.POINTER(oracle.Ext),
+                                           C.c_int, C.c_int, C.c_int, C.c_int]
+        ext = None
+        if fx.get("mode") == "EXT":
+            from cudaraytracing_amd import configs
+            ext = oracle.Ext(**{k: (oracle.Vec3(*v) if isinstance(v, tuple) else v) for k, v in configs.DEFAULT_EXT.items()})
         for s in fx["samples"]:
             x, y = s[0], s[1]
             scr = oracle.Screen(row.ctypes.data, w, 1, w * 16)
-            lib.rco_draw_pixel.argtypes = [C.POINTER(oracle.Screen), C.POINTER(oracle.Scene), C.c_int, C.c_int, C.c_int, C.c_int]
-            lib.rco_draw_pixel(C.byref(scr), C.byref(scene), x, y, y, h)
+            if ext is not None:
+                lib.rco_draw_pixel_ext(C.byref(scr), C.byref(scene), C.byref(ext), x, y, y, h)
+            else:
+                lib.rco_draw_pixel(C.byref(scr), C.byref(scene), x, y, y, h)
             assert row.view(np.uint32)[0, 4 * x: 4 * x + 4].tolist() == s[2:6], (fx["name"], x, y)
         got = np.frombuffer(C.string_at(C.addressof(cam), C.sizeof(cam)), np.uint32).tolist()
         assert got == fx["camera_bits"]
+
+
+def test_ext_mode_reduces_to_plain_search_without_extras(oracle):
+    """EXT with no plane and no shadows finds the same spheres as REF (same hit mask); with the
+    plane, every pixel REF lit is still lit and the floor adds lit pixels."""
+    pos, rad, col = oracle.generate_scene(64, 0)
+    w, h = 320, 180
+    cam = oracle.camera_data((0, 0, 20), (0, 0, 0), w, h)
+    ref = oracle.render(pos, rad, col, cam, w, h)
+    from cudaraytracing_amd import configs
+    d = dict(configs.DEFAULT_EXT, has_plane=0, shadows=0)
+    ext0 = oracle.Ext(**{k: (oracle.Vec3(*v) if isinstance(v, tuple) else v) for k, v in d.items()})
+    e0 = oracle.render(pos, rad, col, cam, w, h, ext=ext0)
+    assert np.array_equal(ref[..., :3].any(axis=2), e0[..., :3].any(axis=2))
+    d = dict(configs.DEFAULT_EXT)
+    ext1 = oracle.Ext(**{k: (oracle.Vec3(*v) if isinstance(v, tuple) else v) for k, v in d.items()})
+    e1 = oracle.render(pos, rad, col, cam, w, h, ext=ext1)
+    lit_ref, lit_ext = ref[..., :3].any(axis=2), e1[..., :3].any(axis=2)
+    assert np.all(lit_ext[lit_ref]) and lit_ext.sum() > lit_ref.sum()
+    assert np.all(e1[..., 3] == 1.0) and not np.isnan(e1).any()
+    # shadows only ever darken
+    d = dict(configs.DEFAULT_EXT, shadows=0)
+    ext2 = oracle.Ext(**{k: (oracle.Vec3(*v) if isinstance(v, tuple) else v) for k, v in d.items()})
+    e2 = oracle.render(pos, rad, col, cam, w, h, ext=ext2)
+    assert np.all(e1[..., :3] <= e2[..., :3]) and (e1[..., :3] < e2[..., :3]).any()
 
 
 def test_row_band_equals_full_frame(oracle):

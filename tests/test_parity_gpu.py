@@ -165,6 +165,84 @@ def test_scene_scale_extremes(oracle, scale):
         assert_same_bits(got, want, f"scale {scale}")
 
 
+# ---- EXT mode (plane, point light, Phong, hard shadows): parity against this repository's own
+# oracle definition; the reference has no such code, so these are "unpinned by the reference".
+
+EXT_VARIANTS = [abi.VARIANT_TILED, abi.VARIANT_TILED2, abi.VARIANT_TILED4, abi.VARIANT_LITERAL]
+
+
+def _default_ext(oracle, **kw):
+    d = dict(configs.DEFAULT_EXT)
+    d.update(kw)
+    return oracle.Ext(**{k: (oracle.Vec3(*v) if isinstance(v, tuple) else v) for k, v in d.items()})
+
+
+@pytest.mark.parametrize("variant", EXT_VARIANTS)
+@pytest.mark.parametrize("name", ["c1_640x480_n8", "c2_1920x1080_n64"])
+def test_ext_benchmark_frames_bit_exact(oracle, golden, name, variant):
+    c, pos, rad, col, cam = _frame(oracle, name)
+    w, h = c["width"], c["height"]
+    ext = _default_ext(oracle)
+    want = oracle.render(pos, rad, col, cam, w, h, ext=ext)
+    got = pixels(gpu_render(pos, rad, col, cam, w, h, variant=variant, ext=ext), w)
+    assert_same_bits(got, want, name + " EXT")
+    assert f"{oracle.fnv_words(got):016x}" == golden[name + "_ext"]["fnv"]
+
+
+@pytest.mark.parametrize("variant", EXT_VARIANTS)
+def test_ext_option_matrix_and_odd_lights(oracle, variant):
+    pos, rad, col = oracle.generate_scene(150, 21)
+    w, h = 400, 226
+    cam = oracle.camera_data((1.0, 2.0, 21.0), (-0.1, 0.05, 0), w, h)
+    cases = [dict(has_plane=0), dict(shadows=0), dict(has_plane=0, shadows=0), dict(shininess_log2=0),
+             dict(shininess_log2=9, specular=1.5),
+             dict(light_pos=tuple(float(v) for v in pos[3])),                  # light inside a sphere
+             dict(light_pos=(0.0, -20.0, 0.0)),                                 # light below the floor
+             dict(plane_normal=(0.0, -2.0, 0.0), plane_h=12.0),                 # non-unit, flipped normal
+             dict(plane_normal=(0.3, 1.0, -0.2), plane_h=-4.0, plane_color=(1.0, 0.2, 0.1)),
+             dict(plane_normal=(0.0, 0.0, 0.0)),                                # degenerate plane: n.d == 0
+             dict(light_pos=(1e6, 1e6, 1e6)), dict(light_pos=(0.0, 0.0, 20.9))]
+    for kw in cases:
+        ext = _default_ext(oracle, **kw)
+        want = oracle.render(pos, rad, col, cam, w, h, ext=ext)
+        got = pixels(gpu_render(pos, rad, col, cam, w, h, variant=variant, ext=ext), w)
+        assert_same_bits(got, want, f"EXT {kw}")
+
+
+def test_ext_random_scenes_stress(oracle):
+    rng = np.random.default_rng(77)
+    w, h = 352, 198
+    for it in range(24):
+        n = int(rng.integers(1, 300))
+        pos = rng.uniform(-12, 12, (n, 3)).astype(np.float32)
+        rad = (10.0 ** rng.uniform(-2, 0.7, n)).astype(np.float32)
+        col = rng.uniform(0, 1, (n, 3)).astype(np.float32)
+        cam = oracle.camera_data(tuple(rng.uniform(-25, 25, 3)), (float(rng.uniform(-3, 3)), float(rng.uniform(-3, 3)), 0.0), w, h)
+        ext = _default_ext(oracle, light_pos=tuple(float(v) for v in rng.uniform(-20, 20, 3)),
+                           plane_normal=tuple(float(v) for v in rng.normal(size=3)), plane_h=float(rng.uniform(-10, 10)))
+        want = oracle.render(pos, rad, col, cam, w, h, ext=ext)
+        variant = [abi.VARIANT_TILED2, abi.VARIANT_TILED4, abi.VARIANT_TILED][it % 3]
+        got = pixels(gpu_render(pos, rad, col, cam, w, h, variant=variant, ext=ext), w)
+        assert_same_bits(got, want, f"EXT stress {it}")
+
+
+def test_ext_ragged_and_multichunk(oracle):
+    for w, h, n in [(333, 77, 5), (65, 17, 0), (96, 64, 4100)]:
+        pos, rad, col = oracle.generate_scene(n, 3)
+        cam = oracle.camera_data((0.5, -0.25, 21.0), (0.05, 0.1, 0.0), w, h)
+        ext = _default_ext(oracle)
+        want = oracle.render(pos, rad, col, cam, w, h, ext=ext)
+        got = pixels(gpu_render(pos, rad, col, cam, w, h, ext=ext), w)
+        assert_same_bits(got, want, f"EXT {w}x{h} n={n}")
+
+
+def test_ext_requires_parameters(rclib):
+    screen = abi.RcScreen(0x1000, 64, 64, 1024)
+    scene = abi.RcScene()
+    assert rclib.rc_render(C.byref(screen), C.byref(scene), C.byref(abi.RcOpts(mode=abi.MODE_EXT))) == abi.RC_EINVAL
+    assert rclib.rc_render(C.byref(screen), C.byref(scene), C.byref(abi.RcOpts(mode=7))) == abi.RC_EINVAL
+
+
 def test_pitch_padding_untouched(oracle):
     pos, rad, col = oracle.generate_scene(16, 1)
     w, h = 100, 40
