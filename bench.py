@@ -48,30 +48,100 @@ def parse():
     ap.add_argument("--mode", default="frames", choices=["frames", "bands"])
     ap.add_argument("--sequence", action="store_true", help="animate the camera along the 300-frame path")
     ap.add_argument("--variant", default="tiled", choices=["tiled", "tiled2", "tiled4", "tiled8", "literal"])
+    ap.add_argument("--shading", default="ref", choices=["ref", "ext"],
+                    help="ref: the reference's math; ext: + plane, point light, Phong, hard shadows (unpinned by the reference)")
+    ap.add_argument("--readback", default="none", choices=["none", "rgba8", "float"],
+                    help="also time K frames end to end through the double-buffered read-back pipeline "
+                         "(reported as end_to_end, never as value)")
     ap.add_argument("--no-cpu", action="store_true", help="skip the cpu_baseline leg")
     ap.add_argument("--cpu-rows", type=int, default=0, help="rows of the frame the CPU baseline renders (0 = auto)")
     return ap.parse_args()
 
 
-def cpu_baseline(cfg, threads):
+def cpu_baseline(cfg, threads, shading):
     """Oracle (port of kernel.cu:21-112) on the host cores, bounded sample of the same frame."""
     from oracle import binding as ob     # the checker, used here only as the timed CPU baseline
     w, h, n = cfg["width"], cfg["height"], cfg["n"]
     pos, rad, col = ob.generate_scene(n, cfg["seed"])
     cam = ob.camera_data(cfg["position"], cfg["rotation"], w, h)
+    ext = None
+    if shading == "ext":
+        ext = ob.Ext(**{k: (ob.Vec3(*v) if isinstance(v, tuple) else v) for k, v in configs.DEFAULT_EXT.items()})
     # ~6.4 ns per test per core: pick rows so the sample is ~20 core-seconds of work
     rows = int(min(h, max(threads, 20.0 / (6.4e-9 * w * max(n, 1)))))
     rows = max(threads, rows - rows % threads)
     y0 = (h - rows) // 2
-    ob.render(pos, rad, col, cam, w, min(rows, 4 * threads), y_offset=y0, full_height=h, threads=threads)  # warm
+    ob.render(pos, rad, col, cam, w, min(rows, 4 * threads), y_offset=y0, full_height=h, threads=threads, ext=ext)  # warm
+    reps, dt = 0, 0.0
     t0 = time.perf_counter()
-    ob.render(pos, rad, col, cam, w, rows, y_offset=y0, full_height=h, threads=threads)
-    dt = time.perf_counter() - t0
+    while dt < 2.0 and reps < 200:          # small frames: repeat until the sample is >= 2 s
+        ob.render(pos, rad, col, cam, w, rows, y_offset=y0, full_height=h, threads=threads, ext=ext)
+        reps += 1
+        dt = time.perf_counter() - t0
+    dt /= reps
     return {
         "value": w * rows / dt / 1e6, "unit": "Mrays/s", "cores": threads, "kind": "port",
-        "sample": f"{rows} centre rows of one {w}x{h} frame, {n} spheres ({w * rows * n / 1e9:.2f} G tests) in {dt:.2f} s",
+        "sample": f"{reps} x {rows} centre rows of one {w}x{h} frame, {n} spheres ({w * rows * n / 1e9:.2f} G tests per pass), {dt:.3f} s per pass",
         "ns_per_test_per_core": dt * threads / (w * rows * max(n, 1)) * 1e9,
     }
+
+
+def pipelined_readback(lib, scene, base_opts, w, h, steps, warmup, what):
+    """K frames rendered AND read back to pinned host memory: two device surfaces, a render
+    stream and a copy stream, the read-back of frame f overlapping the render of frame f+1
+    (the replacement of the reference's sync + full-frame copy, RayTracingKernel.cpp:18-27)."""
+    bpp = 4 if what == "rgba8" else 16
+    render, copy = C.c_void_p(), C.c_void_p()
+    abi.check(lib.rc_stream_create(C.byref(render)))
+    abi.check(lib.rc_stream_create(C.byref(copy)))
+    surf, dev8, host, ev_r, ev_c = [], [], [], [], []
+    for _ in range(2):
+        surf.append(DeviceBuffer(w * 16 * h))
+        dev8.append(DeviceBuffer(w * 4 * h) if what == "rgba8" else None)
+        hp = C.c_void_p()
+        abi.check(lib.rc_host_alloc(C.byref(hp), w * bpp * h))
+        host.append(hp)
+        for lst in (ev_r, ev_c):
+            e = C.c_void_p()
+            abi.check(lib.rc_event_create(C.byref(e)))
+            lst.append(e)
+    opts = abi.RcOpts.from_buffer_copy(bytes(base_opts))
+    opts.ext = base_opts.ext
+    opts.stream = render
+
+    def submit(i):
+        b = i & 1
+        if i >= 2:
+            abi.check(lib.rc_stream_wait_event(render, ev_c[b]))
+        screen = abi.RcScreen(surf[b].ptr.value, w, h, w * 16)
+        if what == "rgba8":
+            opts.rgba8, opts.rgba8_pitch, opts.rgba8_flip = dev8[b].ptr.value, w * 4, 1
+        abi.check(lib.rc_render(C.byref(screen), C.byref(scene), C.byref(opts)), "rc_render")
+        abi.check(lib.rc_event_record(ev_r[b], render))
+        abi.check(lib.rc_stream_wait_event(copy, ev_r[b]))
+        src = dev8[b].ptr if what == "rgba8" else surf[b].ptr
+        abi.check(lib.rc_download_2d_async(host[b], w * bpp, src, w * bpp, w * bpp, h, copy), "download")
+        abi.check(lib.rc_event_record(ev_c[b], copy))
+
+    for i in range(max(warmup, 2)):
+        submit(i)
+    abi.check(lib.rc_sync(None))
+    t0 = time.perf_counter()
+    for i in range(steps):
+        submit(i + 2)
+    abi.check(lib.rc_sync(None))
+    dt = time.perf_counter() - t0
+    for b in range(2):
+        surf[b].free()
+        if dev8[b] is not None:
+            dev8[b].free()
+        lib.rc_host_free(host[b])
+        lib.rc_event_destroy(ev_r[b])
+        lib.rc_event_destroy(ev_c[b])
+    lib.rc_stream_destroy(render)
+    lib.rc_stream_destroy(copy)
+    return {"readback": what, "value": w * h * steps / dt / 1e6, "unit": "Mrays/s", "ms_per_frame": dt / steps * 1e3,
+            "pcie_gbs": w * h * bpp * steps / dt / 1e9, "bytes_per_frame": w * h * bpp}
 
 
 def main():
@@ -122,6 +192,11 @@ def main():
     screen = abi.RcScreen(frame.data_ptr(), w, rows, w * 16)
     stream = torch.cuda.current_stream().cuda_stream
     opts = abi.RcOpts(y_offset=y0, full_height=h, variant=variant, stream=stream)
+    rc_ext = None
+    if args.shading == "ext":
+        rc_ext = abi.RcExt(**{k: (abi.RcVec3(*v) if isinstance(v, tuple) else v) for k, v in configs.DEFAULT_EXT.items()})
+        opts.mode = abi.MODE_EXT
+        opts.ext = C.pointer(rc_ext)
     full = None
     if args.mode == "bands" and world > 1 and rank == 0:
         full = torch.empty((h, w, 4), dtype=torch.float32, device="cuda")
@@ -158,11 +233,21 @@ def main():
 
     dt_max = sharding.max_over_ranks(dt, "cuda")
 
+    end_to_end = None
+    if args.readback != "none" and args.mode == "frames":
+        end_to_end = pipelined_readback(lib, scene, opts, w, h, args.steps, args.warmup, args.readback)
+
     frames_total = args.steps * (world if args.mode == "frames" else 1)
     value = w * h * frames_total / dt_max / 1e6
     kernel_ms = ev_ms.value / args.steps           # HIP events on the launch stream, this rank
     tests = w * rows * n
-    achieved_tflops = FLOP_PER_TEST * tests / (kernel_ms * 1e-3) / 1e12
+    shadow_tests = 0
+    if args.shading == "ext":
+        # one shadow ray per hit pixel, tested against every sphere: 16 FLOP per test (per-ray
+        # origin form); hit pixels counted on the rendered frame
+        hit_pixels = int((frame[..., :3] != 0).any(dim=-1).sum().item())
+        shadow_tests = hit_pixels * n
+    achieved_tflops = (FLOP_PER_TEST * tests + 16 * shadow_tests) / (kernel_ms * 1e-3) / 1e12
     # what the tiled kernel executes per test: (1 + 1/P) FMA (2 FLOP) + one max input (1 FLOP)
     ppl = 8 if w * rows >= 5 * 256 * 128 * 16 else (4 if w * rows >= 5 * 256 * 64 * 16 else 2)
     ppl = {"tiled2": 2, "tiled4": 4, "tiled8": 8}.get(args.variant, ppl)
@@ -187,7 +272,8 @@ def main():
             "ms_per_step": dt_max / args.steps * 1e3, "higher_is_better": True,
             "scaling": "weak" if args.mode == "frames" else "strong",
             "vs_baseline": None, "dtype": "f32", "data": "synthetic",
-            "config": {"workload": args.config, "width": w, "height": h, "spheres": n, "mode": "REF",
+            "config": {"workload": args.config, "width": w, "height": h, "spheres": n,
+                       "mode": "REF" if args.shading == "ref" else "EXT (plane + point light + Phong + hard shadows; unpinned by the reference)",
                        "variant": args.variant, "sharding": args.mode, "camera": "sequence" if args.sequence else "static",
                        "device": name.value.decode(), "compute_units": cu.value, "clock_mhz": khz.value / 1e3},
             "frame_ms": kernel_ms,
@@ -201,13 +287,16 @@ def main():
                 "executed_frac": executed_flop * tests / (kernel_ms * 1e-3) / 1e12 / FP32_VECTOR_PEAK_TFLOPS,
                 "kernel": "rc_draw_tiled<P>" if args.variant == "tiled" else args.variant,
                 "kernel_ms": kernel_ms, "flop_per_test": FLOP_PER_TEST, "tests_per_launch": tests,
+                "shadow_tests_per_launch": shadow_tests,
                 "ref_equiv_tflops_21flop": 21 * tests / (kernel_ms * 1e-3) / 1e12,
                 "hbm_write_gbs": 16.0 * w * rows / (kernel_ms * 1e-3) / 1e9, "hbm_peak_gbs": HBM_PEAK_GBS,
             },
         }
+        if end_to_end is not None:
+            out["end_to_end"] = end_to_end
         if not args.no_cpu and world == 1:
             threads = int(os.environ.get("OMP_NUM_THREADS", "0")) or min(os.cpu_count() or 1, 16)
-            out["cpu_baseline"] = cpu_baseline(cfg, threads)
+            out["cpu_baseline"] = cpu_baseline(cfg, threads, args.shading)
             out["gpu_over_cpu"] = value / out["cpu_baseline"]["value"]
         else:
             out["cpu_baseline"] = None

@@ -75,6 +75,12 @@ SYMBOLS = {
     "rc_upload": (C.c_int, [C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p]),
     "rc_download_2d": (C.c_int, [C.c_void_p, C.c_size_t, C.c_void_p, C.c_size_t, C.c_size_t, C.c_size_t, C.c_void_p]),
     "rc_sync": (C.c_int, [C.c_void_p]),
+    "rc_download_2d_async": (C.c_int, [C.c_void_p, C.c_size_t, C.c_void_p, C.c_size_t, C.c_size_t, C.c_size_t, C.c_void_p]),
+    "rc_stream_create": (C.c_int, [C.POINTER(C.c_void_p)]),
+    "rc_stream_destroy": (C.c_int, [C.c_void_p]),
+    "rc_stream_wait_event": (C.c_int, [C.c_void_p, C.c_void_p]),
+    "rc_host_alloc": (C.c_int, [C.POINTER(C.c_void_p), C.c_size_t]),
+    "rc_host_free": (C.c_int, [C.c_void_p]),
     "rc_event_create": (C.c_int, [C.POINTER(C.c_void_p)]),
     "rc_event_record": (C.c_int, [C.c_void_p, C.c_void_p]),
     "rc_event_elapsed_ms": (C.c_int, [C.c_void_p, C.c_void_p, C.POINTER(C.c_float)]),

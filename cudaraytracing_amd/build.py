@@ -48,7 +48,7 @@ def build(force=False, verbose=False):
         subprocess.run(cmd, check=True, cwd=_ROOT)
     cli_src = os.path.join(CSRC, "host", "rc_render_main.cpp")
     cli_deps = [cli_src, LIB_PATH] + [
-        os.path.join(CSRC, "host", h) for h in ("rc_camera.hpp", "rc_scene_manager.hpp", "rc_raycaster.hpp")
+        os.path.join(CSRC, "host", h) for h in ("rc_camera.hpp", "rc_scene_manager.hpp", "rc_raycaster.hpp", "rc_frame_pipeline.hpp")
     ]
     if os.path.exists(cli_src) and (force or _stale(CLI_PATH, cli_deps)):
         cmd = ["g++", "-O2", "-std=c++17", "-ffp-contract=off", "-I" + os.path.join(_ROOT, "include"),

@@ -2,18 +2,21 @@
 // main.cpp and DXManager.cpp: no window, the frame goes to a PPM file).
 //
 //   rc_render [--width W] [--height H] [--spheres N] [--seed S] [--frames F] [--variant V]
-//             [--pos x,y,z] [--rot pitch,yaw] [--out frame.ppm]
+//             [--pos x,y,z] [--rot pitch,yaw] [--out frame.ppm] [--out-pattern dir/f_%03d.ppm]
 //
 // With --frames F > 1 the camera follows the scripted 300-frame path
 // (theta = 2 pi f / 300: rotation (0.15 sin 2theta, 0.5 sin theta, 0), position
 // (6 sin theta, 1.5 sin 2theta, 20)) and the per-frame time is printed the way the reference
-// prints it (main.cpp:50), here measured with HIP events around the launch only.
+// prints it (main.cpp:50), here measured with HIP events around the launch only.  With
+// --out-pattern every frame of the sequence goes through the double-buffered FramePipeline
+// (render of frame f+1 overlaps the RGBA8 read-back of frame f) and is written as a PPM.
 #include <cmath>
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
 #include <string>
 
+#include "rc_frame_pipeline.hpp"
 #include "rc_raycaster.hpp"
 
 static bool parse3(const char *s, float *a, float *b, float *c)
@@ -26,7 +29,7 @@ int main(int argc, char **argv)
     int w = 1280, h = 768, n = 32 * 16, frames = 1, variant = RC_VARIANT_AUTO;   // main.cpp:32-33, SceneManager.cpp:8
     unsigned seed = 0;
     rc_vec3 pos{0.0f, 0.0f, 20.0f}, rot{0.0f, 0.0f, 0.0f};
-    std::string out = "frame.ppm";
+    std::string out = "frame.ppm", pattern;
     for (int i = 1; i < argc; i++) {
         auto need = [&](const char *flag) -> const char * {
             if (i + 1 >= argc) { std::fprintf(stderr, "%s needs a value\n", flag); std::exit(2); }
@@ -39,6 +42,7 @@ int main(int argc, char **argv)
         else if (!std::strcmp(argv[i], "--frames")) frames = std::atoi(need("--frames"));
         else if (!std::strcmp(argv[i], "--variant")) variant = std::atoi(need("--variant"));
         else if (!std::strcmp(argv[i], "--out")) out = need("--out");
+        else if (!std::strcmp(argv[i], "--out-pattern")) pattern = need("--out-pattern");
         else if (!std::strcmp(argv[i], "--pos")) { if (!parse3(need("--pos"), &pos.x, &pos.y, &pos.z)) return 2; }
         else if (!std::strcmp(argv[i], "--rot")) { float z; const char *v = need("--rot");
             if (std::sscanf(v, "%f,%f", &rot.x, &rot.y) != 2 && !parse3(v, &rot.x, &rot.y, &z)) return 2; }
@@ -52,16 +56,34 @@ int main(int argc, char **argv)
         rtk.sm.cam.position = pos;
         rtk.sm.cam.SetRotation(rot);
         rtk.sm.UpdateCamera();
+        auto path_camera = [&](int f) {
+            const double th = 2.0 * 3.14159265358979323846 * f / 300.0;
+            rtk.sm.cam.position = rc_vec3{(float)(6.0 * std::sin(th)), (float)(1.5 * std::sin(2 * th)), 20.0f};
+            rtk.sm.cam.SetRotation(rc_vec3{(float)(0.15 * std::sin(2 * th)), (float)(0.5 * std::sin(th)), 0.0f});
+            rtk.sm.UpdateCamera();
+        };
+        if (!pattern.empty()) {
+            rc::FramePipeline pipe(w, h, true);
+            auto write = [&](int f, const void *img) {
+                char name[1024];
+                std::snprintf(name, sizeof(name), pattern.c_str(), f);
+                rc::check(rc_write_ppm(name, static_cast<const uint8_t *>(img), (size_t)w * 4, w, h), "rc_write_ppm");
+            };
+            for (int f = 0; f < frames; f++) {
+                path_camera(f);
+                pipe.Submit(rtk.sm.scene, rtk.opts);
+                if (f > 0) write(f - 1, pipe.Collect());
+            }
+            write(frames - 1, pipe.Collect());
+            std::printf("wrote %d pipelined frames (%dx%d, %d spheres)\n", frames, w, h, n);
+            rtk.Cleanup();
+            return 0;
+        }
         void *e0 = nullptr, *e1 = nullptr;
         rc::check(rc_event_create(&e0), "rc_event_create");
         rc::check(rc_event_create(&e1), "rc_event_create");
         for (int f = 0; f < frames; f++) {
-            if (frames > 1) {
-                const double th = 2.0 * 3.14159265358979323846 * f / 300.0;
-                rtk.sm.cam.position = rc_vec3{(float)(6.0 * std::sin(th)), (float)(1.5 * std::sin(2 * th)), 20.0f};
-                rtk.sm.cam.SetRotation(rc_vec3{(float)(0.15 * std::sin(2 * th)), (float)(0.5 * std::sin(th)), 0.0f});
-                rtk.sm.UpdateCamera();
-            }
+            if (frames > 1) path_camera(f);
             rc::check(rc_event_record(e0, nullptr), "rc_event_record");
             rtk.Run(false);
             rc::check(rc_event_record(e1, nullptr), "rc_event_record");

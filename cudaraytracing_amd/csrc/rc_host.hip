@@ -167,9 +167,9 @@ extern "C" int rc_render(const rc_screen *screen, const rc_scene *scene, const r
     case RC_VARIANT_AUTO:
     case RC_VARIANT_TILED: kv = RC_KVARIANT_AUTO; break;
     case RC_VARIANT_LITERAL: kv = RC_KVARIANT_LITERAL; break;
-    case 3: kv = RC_KVARIANT_TILED2; break;   /* tuning: force 2 pixels per lane */
-    case 4: kv = RC_KVARIANT_TILED8; break;   /* tuning: force 8 pixels per lane */
-    case 5: kv = RC_KVARIANT_TILED4; break;   /* tuning: force 4 pixels per lane */
+    case RC_VARIANT_TILED_P2: kv = RC_KVARIANT_TILED2; break;
+    case RC_VARIANT_TILED_P8: kv = RC_KVARIANT_TILED8; break;
+    case RC_VARIANT_TILED_P4: kv = RC_KVARIANT_TILED4; break;
     default: return rc_fail_arg("unknown variant");
     }
 
@@ -355,6 +355,50 @@ extern "C" int rc_download_2d(void *dst_host, size_t dst_pitch, const void *src_
     RC_HIP(hipMemcpy2DAsync(dst_host, dst_pitch, src_device, src_pitch, width_bytes, height,
                             hipMemcpyDeviceToHost, s));
     RC_HIP(hipStreamSynchronize(s));
+    return RC_OK;
+}
+
+extern "C" int rc_download_2d_async(void *dst_host, size_t dst_pitch, const void *src_device, size_t src_pitch,
+                                    size_t width_bytes, size_t height, void *stream)
+{
+    if (!dst_host || !src_device) return rc_fail_arg("null pointer");
+    if (dst_pitch < width_bytes || src_pitch < width_bytes) return rc_fail_arg("pitch < width_bytes");
+    RC_HIP(hipMemcpy2DAsync(dst_host, dst_pitch, src_device, src_pitch, width_bytes, height,
+                            hipMemcpyDeviceToHost, static_cast<hipStream_t>(stream)));
+    return RC_OK;
+}
+
+extern "C" int rc_stream_create(void **stream)
+{
+    if (!stream) return rc_fail_arg("null stream");
+    hipStream_t s;
+    RC_HIP(hipStreamCreateWithFlags(&s, hipStreamNonBlocking));
+    *stream = s;
+    return RC_OK;
+}
+
+extern "C" int rc_stream_destroy(void *stream)
+{
+    RC_HIP(hipStreamDestroy(static_cast<hipStream_t>(stream)));
+    return RC_OK;
+}
+
+extern "C" int rc_stream_wait_event(void *stream, void *event)
+{
+    RC_HIP(hipStreamWaitEvent(static_cast<hipStream_t>(stream), static_cast<hipEvent_t>(event), 0));
+    return RC_OK;
+}
+
+extern "C" int rc_host_alloc(void **ptr, size_t bytes)
+{
+    if (!ptr) return rc_fail_arg("null ptr");
+    RC_HIP(hipHostMalloc(ptr, bytes ? bytes : 1, hipHostMallocDefault));
+    return RC_OK;
+}
+
+extern "C" int rc_host_free(void *ptr)
+{
+    RC_HIP(hipHostFree(ptr));
     return RC_OK;
 }
 

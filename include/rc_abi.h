@@ -66,7 +66,11 @@ typedef struct rc_screen {
 enum {
     RC_VARIANT_AUTO = 0,     /* library picks (the tiled kernel)                          */
     RC_VARIANT_LITERAL = 1,  /* one pixel per lane, every test evaluated as kernel.cu:52-67 */
-    RC_VARIANT_TILED = 2     /* LDS-staged scene, FMA filter + exact re-test (default)     */
+    RC_VARIANT_TILED = 2,    /* LDS-staged scene, FMA filter + exact re-test (default);
+                                pixels per lane chosen from the frame size                 */
+    RC_VARIANT_TILED_P2 = 3, /* tuning: the tiled kernel forced to 2 pixels per lane       */
+    RC_VARIANT_TILED_P8 = 4, /* tuning: forced to 8 pixels per lane (REF mode; EXT uses 4)  */
+    RC_VARIANT_TILED_P4 = 5  /* tuning: forced to 4 pixels per lane                         */
 };
 
 /* Shading modes. */
@@ -146,6 +150,21 @@ int rc_download_2d(void *dst_host, size_t dst_pitch, const void *src_device, siz
                    size_t width_bytes, size_t height, void *stream);
 /* RayTracingKernel.cpp:18 cudaDeviceSynchronize (stream == NULL: whole device) */
 int rc_sync(void *stream);
+
+/* ---- frame pipeline: replaces the reference's render -> device sync -> full-frame copy ->
+ * present sequence (RayTracingKernel.cpp:17-27, main.cpp:47-48) with double-buffered
+ * surfaces whose read-back overlaps the next frame's render.  None of these has a
+ * counterpart in the reference, which uses the default stream only (kernel.cu:123). */
+int rc_stream_create(void **stream);
+int rc_stream_destroy(void *stream);
+/* work submitted to `stream` after this call waits for `event` (recorded on another stream) */
+int rc_stream_wait_event(void *stream, void *event);
+/* page-locked host memory, so that rc_download_2d_async really is asynchronous */
+int rc_host_alloc(void **ptr, size_t bytes);
+int rc_host_free(void *ptr);
+/* rc_download_2d without the wait: returns once the copy is enqueued on `stream` */
+int rc_download_2d_async(void *dst_host, size_t dst_pitch, const void *src_device, size_t src_pitch,
+                         size_t width_bytes, size_t height, void *stream);
 
 /* HIP events on the stream the kernels run on (the reference only has a wall clock,
  * main.cpp:45-50) */

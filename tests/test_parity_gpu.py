@@ -363,6 +363,26 @@ def test_cli_writes_reference_exact_ppm(oracle, tmp_path):
     assert np.array_equal(img, want[..., :3])
 
 
+def test_frame_pipeline_matches_frame_by_frame(oracle, tmp_path):
+    """Double-buffered render/read-back overlap (FramePipeline, through the CLI): every frame of
+    the scripted camera path equals the oracle's frame for that camera."""
+    exe = os.path.join(ROOT, "cudaraytracing_amd", "rc_render")
+    w, h, n, frames = 320, 180, 60, 7
+    pat = str(tmp_path / "f_%03d.ppm")
+    r = subprocess.run([exe, "--width", str(w), "--height", str(h), "--spheres", str(n), "--frames", str(frames),
+                        "--out-pattern", pat], capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, r.stdout + r.stderr
+    pos, rad, col = oracle.generate_scene(n, 0)
+    head = f"P6\n{w} {h}\n255\n".encode()
+    for f in range(frames):
+        data = open(pat % f, "rb").read()
+        img = np.frombuffer(data[len(head):], np.uint8).reshape(h, w, 3)
+        p, rot = configs.sequence_camera(f)
+        cam = oracle.camera_data(p, rot, w, h)
+        want = oracle.to_rgba8(oracle.render(pos, rad, col, cam, w, h), flip=True)
+        assert np.array_equal(img, want[..., :3]), f"frame {f}"
+
+
 def test_argument_validation_on_device(rclib):
     screen = abi.RcScreen(None, 64, 64, 1024)
     scene = abi.RcScene()
