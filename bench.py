@@ -47,7 +47,7 @@ def parse():
     ap.add_argument("--config", default="c3_3840x2160_n1024", choices=sorted(configs.CONFIGS))
     ap.add_argument("--mode", default="frames", choices=["frames", "bands"])
     ap.add_argument("--sequence", action="store_true", help="animate the camera along the 300-frame path")
-    ap.add_argument("--variant", default="tiled", choices=["tiled", "tiled2", "tiled4", "tiled8", "literal"])
+    ap.add_argument("--variant", default="tiled", choices=["tiled", "tiled2", "tiled4", "tiled8", "culled", "literal"])
     ap.add_argument("--shading", default="ref", choices=["ref", "ext"],
                     help="ref: the reference's math; ext: + plane, point light, Phong, hard shadows (unpinned by the reference)")
     ap.add_argument("--readback", default="none", choices=["none", "rgba8", "float"],
@@ -158,15 +158,24 @@ def main():
     import torch.distributed as dist
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU (the HIP path has no CPU fallback)")
+    # Rehearsal switches for a box with fewer GPUs than ranks (never set by the driver):
+    # RC_BENCH_SHARE_GPU=1 puts every rank on device 0, RC_BENCH_BACKEND=gloo replaces RCCL.
+    backend = os.environ.get("RC_BENCH_BACKEND", "nccl")
+    if os.environ.get("RC_BENCH_SHARE_GPU") == "1":
+        local_rank = 0
     torch.cuda.set_device(local_rank)
     lib = abi.load()
     abi.check(lib.rc_set_device(local_rank), "rc_set_device")
     if world > 1:
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        if backend == "nccl":
+            dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        else:
+            dist.init_process_group(backend)
+    comm_device = "cuda" if backend == "nccl" else "cpu"
 
     cfg = configs.CONFIGS[args.config]
     w, h, n = cfg["width"], cfg["height"], cfg["n"]
-    variant = {"tiled": abi.VARIANT_TILED, "tiled2": abi.VARIANT_TILED2, "tiled4": abi.VARIANT_TILED4, "tiled8": abi.VARIANT_TILED8, "literal": abi.VARIANT_LITERAL}[args.variant]
+    variant = {"tiled": abi.VARIANT_TILED, "tiled2": abi.VARIANT_TILED2, "tiled4": abi.VARIANT_TILED4, "tiled8": abi.VARIANT_TILED8, "culled": abi.VARIANT_CULLED, "literal": abi.VARIANT_LITERAL}[args.variant]
 
     # scene resident in HBM before the timed region (SceneManager.cpp:17-24)
     pos, rad, col = generate_scene(n, cfg["seed"])
@@ -208,7 +217,14 @@ def main():
             scene.cam = cam.get_data()                     # SceneManager::UpdateCamera
         abi.check(lib.rc_render(C.byref(screen), C.byref(scene), C.byref(opts)), "rc_render")
         if args.mode == "bands" and world > 1:
-            sharding.gather_bands(frame, full, h, world, rank, dst=0)
+            if comm_device == "cuda":
+                sharding.gather_bands(frame, full, h, world, rank, dst=0)
+            else:                                   # rehearsal backend: stage through host memory
+                torch.cuda.current_stream().synchronize()
+                host_full = torch.empty((h, w, 4), dtype=torch.float32) if rank == 0 else None
+                sharding.gather_bands(frame.cpu(), host_full, h, world, rank, dst=0)
+                if rank == 0:
+                    full.copy_(host_full)
 
     def fence():
         if world > 1:
@@ -231,7 +247,31 @@ def main():
     ev_ms = C.c_float()
     abi.check(lib.rc_event_elapsed_ms(ev0, ev1, C.byref(ev_ms)))
 
-    dt_max = sharding.max_over_ranks(dt, "cuda")
+    dt_max = sharding.max_over_ranks(dt, comm_device)
+
+    # Secondary measurement (N=1, default variant only): the opt-in tile-culling variant on the same
+    # workload.  It is NOT `value`: it no longer performs one test per (pixel, sphere) pair.
+    culled = None
+    if world == 1 and args.variant == "tiled" and args.mode == "frames":
+        copts = abi.RcOpts.from_buffer_copy(bytes(opts))
+        copts.ext = opts.ext
+        copts.variant = abi.VARIANT_CULLED
+        for i in range(max(args.warmup, 3)):
+            abi.check(lib.rc_render(C.byref(screen), C.byref(scene), C.byref(copts)), "rc_render")
+        fence()
+        abi.check(lib.rc_event_record(ev0, stream))
+        for i in range(args.steps):
+            abi.check(lib.rc_render(C.byref(screen), C.byref(scene), C.byref(copts)), "rc_render")
+        abi.check(lib.rc_event_record(ev1, stream))
+        fence()
+        cms = C.c_float()
+        abi.check(lib.rc_event_elapsed_ms(ev0, ev1, C.byref(cms)))
+        cms = cms.value / args.steps
+        culled = {"variant": "culled (RC_VARIANT_CULLED, opt-in): per-wave-tile interval test in front of the per-pixel loop; "
+                             "bit-identical surfaces, not one test per (pixel, sphere) pair",
+                  "value": w * h / (cms * 1e-3) / 1e6, "unit": "Mrays/s", "frame_ms": cms,
+                  "roofline": {"bound": "hbm", "achieved": 16.0 * w * h / (cms * 1e-3) / 1e9, "peak": HBM_PEAK_GBS,
+                               "unit": "GB/s", "frac": 16.0 * w * h / (cms * 1e-3) / 1e9 / HBM_PEAK_GBS}}
 
     end_to_end = None
     if args.readback != "none" and args.mode == "frames":
@@ -274,7 +314,8 @@ def main():
             "vs_baseline": None, "dtype": "f32", "data": "synthetic",
             "config": {"workload": args.config, "width": w, "height": h, "spheres": n,
                        "mode": "REF" if args.shading == "ref" else "EXT (plane + point light + Phong + hard shadows; unpinned by the reference)",
-                       "variant": args.variant, "sharding": args.mode, "camera": "sequence" if args.sequence else "static",
+                       "variant": args.variant, "sharding": args.mode, "backend": backend if world > 1 else None,
+                       "camera": "sequence" if args.sequence else "static",
                        "device": name.value.decode(), "compute_units": cu.value, "clock_mhz": khz.value / 1e3},
             "frame_ms": kernel_ms,
             "roofline": {
@@ -292,6 +333,8 @@ def main():
                 "hbm_write_gbs": 16.0 * w * rows / (kernel_ms * 1e-3) / 1e9, "hbm_peak_gbs": HBM_PEAK_GBS,
             },
         }
+        if culled is not None:
+            out["culled_variant"] = culled
         if end_to_end is not None:
             out["end_to_end"] = end_to_end
         if not args.no_cpu and world == 1:

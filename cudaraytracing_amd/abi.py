@@ -18,6 +18,7 @@ VARIANT_TILED = 2
 VARIANT_TILED2 = 3
 VARIANT_TILED8 = 4
 VARIANT_TILED4 = 5
+VARIANT_CULLED = 6
 
 
 class RcVec3(C.Structure):

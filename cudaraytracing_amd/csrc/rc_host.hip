@@ -170,6 +170,7 @@ extern "C" int rc_render(const rc_screen *screen, const rc_scene *scene, const r
     case RC_VARIANT_TILED_P2: kv = RC_KVARIANT_TILED2; break;
     case RC_VARIANT_TILED_P8: kv = RC_KVARIANT_TILED8; break;
     case RC_VARIANT_TILED_P4: kv = RC_KVARIANT_TILED4; break;
+    case RC_VARIANT_CULLED: kv = RC_KVARIANT_AUTO; break;
     default: return rc_fail_arg("unknown variant");
     }
 
@@ -193,6 +194,7 @@ extern "C" int rc_render(const rc_screen *screen, const rc_scene *scene, const r
     a.rgba8 = o.rgba8;
     a.rgba8_pitch = o.rgba8_pitch;
     a.rgba8_flip = o.rgba8_flip;
+    a.cull = (o.variant == RC_VARIANT_CULLED) ? 1 : 0;
     a.aspect = scene->cam.aspect;
     a.ox = scene->cam.position.x; a.oy = scene->cam.position.y; a.oz = scene->cam.position.z;
     a.fx = scene->cam.forward.x;  a.fy = scene->cam.forward.y;  a.fz = scene->cam.forward.z;

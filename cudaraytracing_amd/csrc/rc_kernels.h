@@ -34,6 +34,7 @@ struct RcKernArgs {
     float nF, nR, nU;        // upper bounds of |forward|, |right|, |up| (filter range check)
     int cam_ok;              // 0: camera basis outside the range the filter is proven for
     // EXT mode (plane + point light + Phong + hard shadows; no counterpart in the reference)
+    int cull;                // 1: tile-culling variant of the tiled kernel
     int ext_mode;            // 0: the reference's shading; 1: EXT
     int has_plane, shadows, shininess_log2;
     float pnx, pny, pnz, plane_h;

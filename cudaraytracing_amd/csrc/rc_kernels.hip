@@ -360,6 +360,19 @@ constexpr int kGroupsPerBlock = kBlockSpheres / kGroup;
 //   int    has_always
 __host__ __device__ constexpr size_t rc_lds_bytes(int cap) { return (size_t)cap * 12 + (size_t)cap + 16; }
 
+__device__ __forceinline__ float rc_wave_min(float v)
+{
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v = fminf(v, __shfl_xor(v, o, 64));
+    return v;
+}
+__device__ __forceinline__ float rc_wave_max(float v)
+{
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o, 64));
+    return v;
+}
+
 // Shadow-ray filter record of one sphere for rays that all start at the light:
 // h = -(light - pos) * k with the same k as above (c taken from the light).  A shadow ray
 // with unit direction e can meet the sphere in front of the light only if h.e >= 1 up to
@@ -492,7 +505,7 @@ __device__ __forceinline__ void rc_shadow_pass(const RcKernArgs &a, char *lds,
     }
 }
 
-template <int P, bool EXT>
+template <int P, bool EXT, bool CULL>
 __device__ __forceinline__ void rc_tiled_body(const RcKernArgs &a, char *lds)
 {
     constexpr int TW = 8 * P;   // wave tile width in pixels
@@ -544,6 +557,20 @@ __device__ __forceinline__ void rc_tiled_body(const RcKernArgs &a, char *lds)
         const rc_f2 bb = {fb, fb};
         const unsigned long long forced_mask = __builtin_amdgcn_ballot_w64(lane_forced);
 
+        // wave-tile interval bounds of the filter inputs (used by the culling variant only)
+        float ta_lo = 0.0f, ta_hi = 0.0f, tb_lo = 0.0f, tb_hi = 0.0f, ta_abs = 0.0f, tb_abs = 0.0f, tlen_min = 0.0f;
+        const bool tile_forced = (forced_mask != 0ull);
+        if (CULL) {
+            float lo = fa[0], hi = fa[0], lm = len[0];
+#pragma unroll
+            for (int p = 1; p < P; p++) { lo = fminf(lo, fa[p]); hi = fmaxf(hi, fa[p]); lm = fminf(lm, len[p]); }
+            ta_lo = rc_wave_min(lo); ta_hi = rc_wave_max(hi);
+            tb_lo = rc_wave_min(fb); tb_hi = rc_wave_max(fb);
+            tlen_min = rc_wave_min(lm);
+            ta_abs = fmaxf(fabsf(ta_lo), fabsf(ta_hi));
+            tb_abs = fmaxf(fabsf(tb_lo), fabsf(tb_hi));
+        }
+
         for (int base = 0; base < a.n; base += cap) {
             const int cn = min(a.n - base, cap);
             const int cnb = (cn + kBlockSpheres - 1) & ~(kBlockSpheres - 1);   // whole blocks
@@ -567,6 +594,48 @@ __device__ __forceinline__ void rc_tiled_body(const RcKernArgs &a, char *lds)
             const unsigned long long flag0_mask = (*s_has_always != 0) ? ~0ull : forced_mask;
             const int nblocks = cnb / kBlockSpheres;
 
+            if (CULL) {
+                // Tile culling (opt-in variant): the same separable filter evaluated ONCE PER WAVE
+                // TILE with interval bounds instead of once per pixel.  Over the tile a lies in
+                // [a_lo, a_hi], b in [b_lo, b_hi] and len >= len_min, and T is linear in a and in
+                // b, so T <= alpha + max(b_lo gamma, b_hi gamma) + max(a_lo beta, a_hi beta) = Tmax.
+                // A sphere whose Tmax (plus 16u of the summed magnitudes for the roundings of T and
+                // Tmax) stays below len_min is flagged by no pixel of the tile.  Lane l tests sphere
+                // 64 it + l; survivors are visited in ascending index with the per-pixel filter and
+                // the exact test, so the result is that of the brute-force loop.
+                const int iters = (cn + 63) >> 6;
+                const float *rec = reinterpret_cast<const float *>(s_rec);
+                const unsigned char *flagb = reinterpret_cast<const unsigned char *>(s_flag);
+                for (int it = 0; it < iters; it++) {
+                    const int jl = (it << 6) + lane;
+                    unsigned long long cand_mask;
+                    {
+                        const int jc = min(jl, cnb - 1);
+                        const float *g = rec + (jc >> 2) * 12 + (jc & 3);
+                        const float al = g[0], ga = g[4], be = g[8];
+                        const float tmax = (al + fmaxf(tb_lo * ga, tb_hi * ga)) + fmaxf(ta_lo * be, ta_hi * be);
+                        const float mag = (fabsf(al) + tb_abs * fabsf(ga)) + ta_abs * fabsf(be);
+                        const bool c = (jl < cn) && (tile_forced || flagb[jc] != 0 || (tmax + 0x1p-20f * mag >= tlen_min));
+                        cand_mask = __builtin_amdgcn_ballot_w64(c);
+                    }
+                    while (cand_mask != 0ull) {
+                        const int bit = __builtin_ctzll(cand_mask);
+                        cand_mask &= cand_mask - 1ull;
+                        const int j = (it << 6) + bit;                 // wave-uniform
+                        const float *g = rec + (j >> 2) * 12 + (j & 3);
+                        const float r = __builtin_fmaf(fb, g[4], g[0]);
+                        const float be = g[8];
+                        bool cand = lane_forced || (flagb[j] != 0);
+#pragma unroll
+                        for (int p = 0; p < P; p++) cand = cand || (__builtin_fmaf(fa[p], be, r) >= len[p]);
+                        if (__builtin_amdgcn_ballot_w64(cand) == 0ull) continue;
+                        const RcExactSphere e = rc_exact_sphere(a, base + j);
+#pragma unroll
+                        for (int p = 0; p < P; p++)
+                            rc_exact_test(e, dx[p], dy[p], dz[p], base + j, minDist[p], idx[p]);
+                    }
+                }
+            } else
             for (int blk = 0; blk < nblocks; blk++) {
                 float m[P];
 #pragma unroll
@@ -672,11 +741,11 @@ __device__ __forceinline__ void rc_tiled_body(const RcKernArgs &a, char *lds)
 
 } // namespace
 
-template <int P, bool EXT>
+template <int P, bool EXT, bool CULL>
 __global__ __launch_bounds__(256) void rc_draw_tiled(RcKernArgs a)
 {
     extern __shared__ __attribute__((aligned(16))) char rc_lds[];
-    rc_tiled_body<P, EXT>(a, rc_lds);
+    rc_tiled_body<P, EXT, CULL>(a, rc_lds);
 }
 
 // float RGBA -> RGBA8 (the display step that follows the path in the reference)
@@ -712,12 +781,15 @@ static hipError_t rc_launch_tiled(RcKernArgs a, hipStream_t stream)
     a.tiles_y = (a.rows + 15) / 16;
     const unsigned grid = (unsigned)rc_tile_count<P>(a);
     if (a.ext_mode) {
-        if constexpr (P <= 4)
-            hipLaunchKernelGGL((rc_draw_tiled<P, true>), dim3(grid), dim3(256), rc_lds_bytes(a.lds_cap), stream, a);
-        else
+        if constexpr (P <= 4) {
+            if (a.cull) hipLaunchKernelGGL((rc_draw_tiled<P, true, true>), dim3(grid), dim3(256), rc_lds_bytes(a.lds_cap), stream, a);
+            else hipLaunchKernelGGL((rc_draw_tiled<P, true, false>), dim3(grid), dim3(256), rc_lds_bytes(a.lds_cap), stream, a);
+        } else {
             return hipErrorInvalidValue;           // EXT is built for <= 4 pixels per lane
+        }
     } else {
-        hipLaunchKernelGGL((rc_draw_tiled<P, false>), dim3(grid), dim3(256), rc_lds_bytes(a.lds_cap), stream, a);
+        if (a.cull) hipLaunchKernelGGL((rc_draw_tiled<P, false, true>), dim3(grid), dim3(256), rc_lds_bytes(a.lds_cap), stream, a);
+        else hipLaunchKernelGGL((rc_draw_tiled<P, false, false>), dim3(grid), dim3(256), rc_lds_bytes(a.lds_cap), stream, a);
     }
     return hipGetLastError();
 }

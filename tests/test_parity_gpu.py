@@ -18,7 +18,8 @@ from gpu_util import GpuScene, assert_same_bits, gpu_render, pixels
 
 pytestmark = pytest.mark.gpu
 
-VARIANTS = [abi.VARIANT_TILED, abi.VARIANT_TILED2, abi.VARIANT_TILED4, abi.VARIANT_TILED8, abi.VARIANT_LITERAL]
+VARIANTS = [abi.VARIANT_TILED, abi.VARIANT_TILED2, abi.VARIANT_TILED4, abi.VARIANT_TILED8, abi.VARIANT_CULLED,
+            abi.VARIANT_LITERAL]
 
 
 def _frame(oracle, name):
@@ -148,6 +149,8 @@ def test_random_scenes_and_cameras_stress(oracle):
         variant = [abi.VARIANT_TILED2, abi.VARIANT_TILED4, abi.VARIANT_TILED8][it % 3]
         got = pixels(gpu_render(pos, rad, col, cam, w, h, variant=variant), w)
         assert_same_bits(got, want, f"stress scene {it} (n={n}, cam={cpos}, rot={rot})")
+        got = pixels(gpu_render(pos, rad, col, cam, w, h, variant=abi.VARIANT_CULLED), w)
+        assert_same_bits(got, want, f"stress scene {it}, culled (n={n}, cam={cpos}, rot={rot})")
 
 
 @pytest.mark.parametrize("scale", [1e-12, 1e-6, 1e-3, 1e3, 1e6, 1e12, 1e18])
@@ -160,7 +163,7 @@ def test_scene_scale_extremes(oracle, scale):
     w, h = 320, 180
     cam = oracle.camera_data(tuple(np.float32([0.3, -0.2, 20.0]) * s), (0.02, 0.03, 0), w, h)
     want = oracle.render(pos * s, rad * s, col, cam, w, h)
-    for variant in (abi.VARIANT_TILED4, abi.VARIANT_TILED8):
+    for variant in (abi.VARIANT_TILED4, abi.VARIANT_TILED8, abi.VARIANT_CULLED):
         got = pixels(gpu_render(pos * s, rad * s, col, cam, w, h, variant=variant), w)
         assert_same_bits(got, want, f"scale {scale}")
 
@@ -168,7 +171,7 @@ def test_scene_scale_extremes(oracle, scale):
 # ---- EXT mode (plane, point light, Phong, hard shadows): parity against this repository's own
 # oracle definition; the reference has no such code, so these are "unpinned by the reference".
 
-EXT_VARIANTS = [abi.VARIANT_TILED, abi.VARIANT_TILED2, abi.VARIANT_TILED4, abi.VARIANT_LITERAL]
+EXT_VARIANTS = [abi.VARIANT_TILED, abi.VARIANT_TILED2, abi.VARIANT_TILED4, abi.VARIANT_CULLED, abi.VARIANT_LITERAL]
 
 
 def _default_ext(oracle, **kw):
@@ -319,6 +322,8 @@ def test_full_size_golden_hashes(oracle, golden, name):
     flat = np.ascontiguousarray(rgba8).view(np.uint32).reshape(1, -1)
     scr = oracle.Screen(flat.ctypes.data, flat.shape[1] // 4, 1, flat.shape[1] * 4)
     assert f"{int(oracle.load().rco_fnv1a64_words(C.byref(scr), oracle.FNV_BASIS)):016x}" == fx["rgba8_flip_fnv"]
+    culled = pixels(gpu_render(pos, rad, col, cam, w, h, variant=abi.VARIANT_CULLED, scene=scene), w)
+    assert_same_bits(culled, got, "culled vs tiled")
     if name.startswith("c3") or name.startswith("c4"):
         lit = pixels(gpu_render(pos, rad, col, cam, w, h, variant=abi.VARIANT_LITERAL, scene=scene), w)
         assert_same_bits(lit, got, "literal vs tiled")
