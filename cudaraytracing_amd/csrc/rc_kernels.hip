@@ -313,7 +313,8 @@ namespace {
 //  * T differs from k(-(v.q)) by <= 12ukLQ <= 48uk L len: 5u for the float records (dot product
 //    3u, k and its product 2u), u for a, 2u for the two fma roundings, 4u for q itself;
 //  hence T >= k len (sqrt(c)(1-2u) - 52.1uL).  The record uses
-//      k = 1 / thr,   thr = sqrt(c)(1 - 2^-19) - 2^-17 sqrt(v.v)   (all binary32, <= 3u error)
+//      k = 1 / thr,   thr = sqrt(c)(1 - 2^-19) - 2^-17 sqrt(v.v)
+//  evaluated in binary32 with the hardware's 1-ulp sqrt and reciprocal (<= 8u error in all),
 //  which is below sqrt(c)(1-5u) - 64uL, so k(...) >= 1 and T >= len whenever the exact test hits.
 // Spheres where thr <= 0 or any quantity leaves the range in which these bounds hold (camera
 // inside or within ~1e-5 relative of the surface, non-finite data, |v|^2 outside [2^-80, 2^80],
@@ -331,10 +332,11 @@ __device__ __forceinline__ RcRecord rc_prepass_sphere(const RcKernArgs &a, int i
     float vx = a.ox - px, vy = a.oy - py, vz = a.oz - pz;
     float vv = (vx * vx + vy * vy) + vz * vz;
     float c = vv - r * r;                                   // the reference's c, as rounded
-    float thr = sqrtf(c) * (1.0f - 0x1p-19f) - 0x1p-17f * sqrtf(vv);
+    // hardware sqrt / reciprocal (1 ulp each) are enough here: the margins below absorb them
+    float thr = __builtin_amdgcn_sqrtf(c) * (1.0f - 0x1p-19f) - 0x1p-17f * __builtin_amdgcn_sqrtf(vv);
     RcRecord rec;
     rec.always = !(c > 0.0f) || !(thr > 0.0f) || !(vv < 0x1p80f) || !(vv > 0x1p-80f);
-    float k = 1.0f / thr;
+    float k = __builtin_amdgcn_rcpf(thr);
     float vF = __builtin_fmaf(vz, a.fz, __builtin_fmaf(vy, a.fy, vx * a.fx));
     float vR = __builtin_fmaf(vz, a.rz, __builtin_fmaf(vy, a.ry, vx * a.rx));
     float vU = __builtin_fmaf(vz, a.uz, __builtin_fmaf(vy, a.uy, vx * a.ux));
@@ -351,7 +353,7 @@ typedef float rc_f2 __attribute__((ext_vector_type(2)));
 
 __device__ __forceinline__ rc_f2 rc_fma2(rc_f2 x, rc_f2 y, rc_f2 z) { return __builtin_elementwise_fma(x, y, z); }
 
-constexpr int kBlockSpheres = 16;                       // spheres between two flag checks
+constexpr int kBlockSpheres = 32;                       // spheres between two flag checks
 constexpr int kGroupsPerBlock = kBlockSpheres / kGroup;
 
 // LDS image of a chunk of `cap` spheres (cap a multiple of 16):
@@ -359,6 +361,27 @@ constexpr int kGroupsPerBlock = kBlockSpheres / kGroup;
 //   uint   flag[cap/4]    per group, byte s = "always" flag of sphere s
 //   int    has_always
 __host__ __device__ constexpr size_t rc_lds_bytes(int cap) { return (size_t)cap * 12 + (size_t)cap + 16; }
+
+// One sphere the tile-level test could not rule out: per-pixel filter, then the exact test if
+// some lane still flags it.  j is wave-uniform (index inside the LDS chunk).
+template <int P>
+__device__ __forceinline__ void rc_visit_sphere(const RcKernArgs &a, const float *rec, const unsigned char *flagb,
+                                                int j, int base, bool lane_forced,
+                                                const float (&fa)[P], float fb, const float (&len)[P],
+                                                const float (&dx)[P], const float (&dy)[P], const float (&dz)[P],
+                                                float (&minDist)[P], int (&idx)[P])
+{
+    const float *g = rec + (j >> 2) * 12 + (j & 3);
+    const float r = __builtin_fmaf(fb, g[4], g[0]);
+    const float be = g[8];
+    bool cand = lane_forced || (flagb[j] != 0);
+#pragma unroll
+    for (int p = 0; p < P; p++) cand = cand || (__builtin_fmaf(fa[p], be, r) >= len[p]);
+    if (__builtin_amdgcn_ballot_w64(cand) == 0ull) return;
+    const RcExactSphere e = rc_exact_sphere(a, base + j);
+#pragma unroll
+    for (int p = 0; p < P; p++) rc_exact_test(e, dx[p], dy[p], dz[p], base + j, minDist[p], idx[p]);
+}
 
 __device__ __forceinline__ float rc_wave_min(float v)
 {
@@ -387,10 +410,10 @@ __device__ __forceinline__ RcLightRecord rc_prepass_light(const RcKernArgs &a, i
     float vx = a.lgx - px, vy = a.lgy - py, vz = a.lgz - pz;
     float vv = (vx * vx + vy * vy) + vz * vz;
     float c = vv - r * r;
-    float thr = sqrtf(c) * (1.0f - 0x1p-19f) - 0x1p-17f * sqrtf(vv);
+    float thr = __builtin_amdgcn_sqrtf(c) * (1.0f - 0x1p-19f) - 0x1p-17f * __builtin_amdgcn_sqrtf(vv);
     RcLightRecord rec;
     rec.always = !(c > 0.0f) || !(thr > 0.0f) || !(vv < 0x1p80f) || !(vv > 0x1p-80f);
-    float k = 1.0f / thr;
+    float k = __builtin_amdgcn_rcpf(thr);
     rec.hx = -k * vx; rec.hy = -k * vy; rec.hz = -k * vz;
     rec.always = rec.always || !(fabsf(rec.hx) < 0x1p40f) || !(fabsf(rec.hy) < 0x1p40f) || !(fabsf(rec.hz) < 0x1p40f);
     if (rec.always) { rec.hx = 0.0f; rec.hy = 0.0f; rec.hz = 0.0f; }
@@ -557,10 +580,14 @@ __device__ __forceinline__ void rc_tiled_body(const RcKernArgs &a, char *lds)
         const rc_f2 bb = {fb, fb};
         const unsigned long long forced_mask = __builtin_amdgcn_ballot_w64(lane_forced);
 
-        // wave-tile interval bounds of the filter inputs (used by the culling variant only)
-        float ta_lo = 0.0f, ta_hi = 0.0f, tb_lo = 0.0f, tb_hi = 0.0f, ta_abs = 0.0f, tb_abs = 0.0f, tlen_min = 0.0f;
+        // Wave-tile interval bounds of the filter inputs.  Over the tile a lies in [ta_lo, ta_hi],
+        // b in [tb_lo, tb_hi] and len >= tlen_min, and T = alpha + b gamma + a beta is linear in a
+        // and in b, so T <= alpha + max(tb_lo gamma, tb_hi gamma) + max(ta_lo beta, ta_hi beta) =
+        // Tmax for every pixel of the tile.  A sphere whose Tmax, plus 16u of the summed magnitudes
+        // for the roundings of T and Tmax, stays below tlen_min is flagged by no pixel of the tile.
+        float ta_lo, ta_hi, tb_lo, tb_hi, ta_abs, tb_abs, tlen_min;
         const bool tile_forced = (forced_mask != 0ull);
-        if (CULL) {
+        {
             float lo = fa[0], hi = fa[0], lm = len[0];
 #pragma unroll
             for (int p = 1; p < P; p++) { lo = fminf(lo, fa[p]); hi = fmaxf(hi, fa[p]); lm = fminf(lm, len[p]); }
@@ -595,14 +622,10 @@ __device__ __forceinline__ void rc_tiled_body(const RcKernArgs &a, char *lds)
             const int nblocks = cnb / kBlockSpheres;
 
             if (CULL) {
-                // Tile culling (opt-in variant): the same separable filter evaluated ONCE PER WAVE
-                // TILE with interval bounds instead of once per pixel.  Over the tile a lies in
-                // [a_lo, a_hi], b in [b_lo, b_hi] and len >= len_min, and T is linear in a and in
-                // b, so T <= alpha + max(b_lo gamma, b_hi gamma) + max(a_lo beta, a_hi beta) = Tmax.
-                // A sphere whose Tmax (plus 16u of the summed magnitudes for the roundings of T and
-                // Tmax) stays below len_min is flagged by no pixel of the tile.  Lane l tests sphere
-                // 64 it + l; survivors are visited in ascending index with the per-pixel filter and
-                // the exact test, so the result is that of the brute-force loop.
+                // Tile culling (opt-in variant): the interval test of the wave tile replaces the
+                // per-pixel loop.  Lane l tests sphere 64 it + l; survivors are visited in ascending
+                // index with the per-pixel filter and the exact test, so the result is that of the
+                // brute-force loop.
                 const int iters = (cn + 63) >> 6;
                 const float *rec = reinterpret_cast<const float *>(s_rec);
                 const unsigned char *flagb = reinterpret_cast<const unsigned char *>(s_flag);
@@ -621,18 +644,8 @@ __device__ __forceinline__ void rc_tiled_body(const RcKernArgs &a, char *lds)
                     while (cand_mask != 0ull) {
                         const int bit = __builtin_ctzll(cand_mask);
                         cand_mask &= cand_mask - 1ull;
-                        const int j = (it << 6) + bit;                 // wave-uniform
-                        const float *g = rec + (j >> 2) * 12 + (j & 3);
-                        const float r = __builtin_fmaf(fb, g[4], g[0]);
-                        const float be = g[8];
-                        bool cand = lane_forced || (flagb[j] != 0);
-#pragma unroll
-                        for (int p = 0; p < P; p++) cand = cand || (__builtin_fmaf(fa[p], be, r) >= len[p]);
-                        if (__builtin_amdgcn_ballot_w64(cand) == 0ull) continue;
-                        const RcExactSphere e = rc_exact_sphere(a, base + j);
-#pragma unroll
-                        for (int p = 0; p < P; p++)
-                            rc_exact_test(e, dx[p], dy[p], dz[p], base + j, minDist[p], idx[p]);
+                        rc_visit_sphere<P>(a, rec, flagb, (it << 6) + bit, base, lane_forced, fa, fb, len,
+                                           dx, dy, dz, minDist, idx);
                     }
                 }
             } else
@@ -660,42 +673,29 @@ __device__ __forceinline__ void rc_tiled_body(const RcKernArgs &a, char *lds)
 #pragma unroll
                 for (int p = 0; p < P; p++) flagged |= __builtin_amdgcn_ballot_w64(m[p] >= len[p]);
                 if (flagged != 0ull) {
-                    // Rare path: some lane cannot rule out some sphere of this block.  Redo the
-                    // filter group by group (same fma, same bits), this time keeping one
-                    // wave-wide mask per sphere, and run the reference's exact test for every
-                    // sphere some lane still flags.
-#pragma nounroll
-                    for (int g = 0; g < kGroupsPerBlock; g++) {
-                        const int gi = blk * kGroupsPerBlock + g;
-                        if (gi * kGroup >= cn) break;
-                        const float4 A = s_rec[gi * 3 + 0];
-                        const float4 G = s_rec[gi * 3 + 1];
-                        const float4 B = s_rec[gi * 3 + 2];
-                        const unsigned fl = __builtin_amdgcn_readfirstlane(s_flag[gi]);
-                        const rc_f2 r01 = rc_fma2(bb, rc_f2{G.x, G.y}, rc_f2{A.x, A.y});
-                        const rc_f2 r23 = rc_fma2(bb, rc_f2{G.z, G.w}, rc_f2{A.z, A.w});
-                        unsigned long long cm[kGroup];
-#pragma unroll
-                        for (int s = 0; s < kGroup; s++) cm[s] = ((fl >> (8 * s)) & 0xffu) ? ~0ull : forced_mask;
-#pragma unroll
-                        for (int p = 0; p < P; p++) {
-                            const rc_f2 aa = {fa[p], fa[p]};
-                            const rc_f2 t01 = rc_fma2(aa, rc_f2{B.x, B.y}, r01);
-                            const rc_f2 t23 = rc_fma2(aa, rc_f2{B.z, B.w}, r23);
-                            cm[0] |= __builtin_amdgcn_ballot_w64(t01.x >= len[p]);
-                            cm[1] |= __builtin_amdgcn_ballot_w64(t01.y >= len[p]);
-                            cm[2] |= __builtin_amdgcn_ballot_w64(t23.x >= len[p]);
-                            cm[3] |= __builtin_amdgcn_ballot_w64(t23.y >= len[p]);
-                        }
-#pragma unroll
-                        for (int s = 0; s < kGroup; s++) {
-                            const int j = gi * kGroup + s;
-                            if (cm[s] == 0ull || j >= cn) continue;
-                            const RcExactSphere e = rc_exact_sphere(a, base + j);
-#pragma unroll
-                            for (int p = 0; p < P; p++)
-                                rc_exact_test(e, dx[p], dy[p], dz[p], base + j, minDist[p], idx[p]);
-                        }
+                    // Rare path: some lane cannot rule out some sphere of this block.  Find which
+                    // spheres: lane l tests sphere l of the block against the wave tile's interval
+                    // bounds computed above (a superset of what any pixel flags), then each survivor
+                    // gets the per-pixel filter again (same fma, same bits) and, if a lane still
+                    // flags it, the reference's exact test.
+                    const float *rec = reinterpret_cast<const float *>(s_rec);
+                    const unsigned char *flagb = reinterpret_cast<const unsigned char *>(s_flag);
+                    const int jl = blk * kBlockSpheres + (lane & (kBlockSpheres - 1));
+                    unsigned long long cand_mask;
+                    {
+                        const float *g = rec + (jl >> 2) * 12 + (jl & 3);
+                        const float al = g[0], ga = g[4], be = g[8];
+                        const float tmax = (al + fmaxf(tb_lo * ga, tb_hi * ga)) + fmaxf(ta_lo * be, ta_hi * be);
+                        const float mag = (fabsf(al) + tb_abs * fabsf(ga)) + ta_abs * fabsf(be);
+                        const bool c = (lane < kBlockSpheres) && (jl < cn) &&
+                                       (tile_forced || flagb[jl] != 0 || (tmax + 0x1p-20f * mag >= tlen_min));
+                        cand_mask = __builtin_amdgcn_ballot_w64(c);
+                    }
+                    while (cand_mask != 0ull) {
+                        const int bit = __builtin_ctzll(cand_mask);
+                        cand_mask &= cand_mask - 1ull;
+                        rc_visit_sphere<P>(a, rec, flagb, blk * kBlockSpheres + bit, base, lane_forced, fa, fb, len,
+                                           dx, dy, dz, minDist, idx);
                     }
                 }
             }
