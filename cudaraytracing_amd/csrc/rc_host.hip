@@ -65,7 +65,7 @@ struct SinTables {
 std::mutex g_mu;
 std::vector<SinTables> g_tables;
 uint64_t g_tick = 0;
-constexpr size_t kMaxTables = 32;
+constexpr size_t kMaxTables = 32;   // per device
 
 int rc_get_tables(float fov, int width, int full_height, const float **sx, const float **sy)
 {
@@ -82,18 +82,18 @@ int rc_get_tables(float fov, int width, int full_height, const float **sx, const
             return RC_OK;
         }
     }
-    if (g_tables.size() >= kMaxTables) {
-        // evict the least recently used entry of this device; frames that still read it
-        // must have finished first
+    size_t mine = 0;
+    for (const auto &t : g_tables) mine += (t.device == dev);
+    if (mine >= kMaxTables) {
+        // evict this device's least recently used entry; frames that still read it must have
+        // finished first
         size_t victim = g_tables.size();
         for (size_t i = 0; i < g_tables.size(); i++)
             if (g_tables[i].device == dev && (victim == g_tables.size() || g_tables[i].last_use < g_tables[victim].last_use))
                 victim = i;
-        if (victim != g_tables.size()) {
-            RC_HIP(hipDeviceSynchronize());
-            RC_HIP(hipFree(g_tables[victim].d_base));
-            g_tables.erase(g_tables.begin() + (long)victim);
-        }
+        RC_HIP(hipDeviceSynchronize());
+        RC_HIP(hipFree(g_tables[victim].d_base));
+        g_tables.erase(g_tables.begin() + (long)victim);
     }
     std::vector<float> h((size_t)width + (size_t)full_height);
     for (int x = 0; x < width; x++)

@@ -461,7 +461,7 @@ __device__ __forceinline__ void rc_shadow_pass(const RcKernArgs &a, char *lds,
                 float *g = rec + (j >> 2) * 12 + (j & 3);
                 g[0] = r.hx; g[4] = r.hy; g[8] = r.hz;
                 flagb[j] = r.always ? 1 : 0;
-                if (r.always) *s_has_always = 1;
+                if (r.always) atomicOr(s_has_always, 1);
             }
         }
         __syncthreads();
@@ -614,7 +614,7 @@ __device__ __forceinline__ void rc_tiled_body(const RcKernArgs &a, char *lds)
                     float *g = rec + (j >> 2) * 12 + (j & 3);
                     g[0] = r.alpha; g[4] = r.gamma; g[8] = r.beta;
                     flagb[j] = r.always ? 1 : 0;
-                    if (r.always) *s_has_always = 1;
+                    if (r.always) atomicOr(s_has_always, 1);
                 }
                 __syncthreads();
             }

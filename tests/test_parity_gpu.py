@@ -153,6 +153,37 @@ def test_random_scenes_and_cameras_stress(oracle):
         assert_same_bits(got, want, f"stress scene {it}, culled (n={n}, cam={cpos}, rot={rot})")
 
 
+def test_filter_soak_tiled_vs_literal_on_device(oracle):
+    """600 random scenes: every filtered variant against the unfiltered literal kernel, both on
+    the GPU (the literal kernel is itself held to the oracle above).  Cameras are placed at
+    random distances from a random sphere's surface, down to 1e-7 relative, to stress the
+    hand-over between the filter and the exact path."""
+    rng = np.random.default_rng(99)
+    w, h = 192, 104
+    variants = [abi.VARIANT_TILED2, abi.VARIANT_TILED4, abi.VARIANT_TILED8, abi.VARIANT_CULLED]
+    for it in range(600):
+        n = int(rng.integers(1, 120))
+        spread = 10.0 ** rng.uniform(-1, 2)
+        pos = rng.uniform(-spread, spread, (n, 3)).astype(np.float32)
+        rad = (spread * 10.0 ** rng.uniform(-3, 0, n)).astype(np.float32)
+        col = rng.uniform(0, 1, (n, 3)).astype(np.float32)
+        k = int(rng.integers(n))
+        dirv = rng.normal(size=3); dirv /= np.linalg.norm(dirv)
+        off = 1.0 + rng.choice([-1.0, 1.0]) * 10.0 ** rng.uniform(-7, 1)
+        cpos = tuple(float(v) for v in (pos[k] + dirv * rad[k] * off))
+        if it % 2 == 0:      # look at the sphere
+            f = -dirv
+            rot = (float(np.arcsin(np.clip(f[1], -1, 1))), float(np.arctan2(-f[0], -f[2])), 0.0)
+        else:
+            rot = (float(rng.uniform(-3.2, 3.2)), float(rng.uniform(-3.2, 3.2)), 0.0)
+        cam = oracle.camera_data(cpos, rot, w, h)
+        scene = GpuScene(pos, rad, col)
+        want = pixels(gpu_render(pos, rad, col, cam, w, h, variant=abi.VARIANT_LITERAL, scene=scene), w)
+        got = pixels(gpu_render(pos, rad, col, cam, w, h, variant=variants[it % 4], scene=scene), w)
+        scene.free()
+        assert_same_bits(got, want, f"soak {it}: n={n} cam={cpos} rot={rot} variant={variants[it % 4]}")
+
+
 @pytest.mark.parametrize("scale", [1e-12, 1e-6, 1e-3, 1e3, 1e6, 1e12, 1e18])
 def test_scene_scale_extremes(oracle, scale):
     """Coordinates from 1e-12 to 1e18: the filter's range checks must hand over to the exact

@@ -5,7 +5,7 @@ cp $ORIG /tmp/librc_orig.so
 for round in 1 2 3; do
   for lib in /tmp/librc_orig.so "$@"; do
     cp $lib $ORIG
-    for v in tiled4 tiled8; do
+    for v in tiled8; do
       python bench.py --steps 200 --warmup 20 --variant $v --no-cpu 2>/dev/null | python -c "
 import sys,json
 d=json.loads(sys.stdin.readline()); print('$lib', d['config']['variant'], round(d['frame_ms'],4))"
