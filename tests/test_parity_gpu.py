@@ -419,6 +419,73 @@ def test_frame_pipeline_matches_frame_by_frame(oracle, tmp_path):
         assert np.array_equal(img, want[..., :3]), f"frame {f}"
 
 
+def test_concurrent_calls_from_threads_and_streams(oracle):
+    """rc_render keeps no per-frame state: four host threads, each with its own stream, scene,
+    camera and frame size, render at the same time; every frame must still match the oracle."""
+    import threading
+    lib = abi.load()
+    jobs = []
+    for t in range(4):
+        w, h, n = 300 + 37 * t, 170 + 11 * t, 60 + 50 * t
+        pos, rad, col = oracle.generate_scene(n, 100 + t)
+        cam = oracle.camera_data((0.3 * t, -0.2 * t, 20.0 + t), (0.02 * t, -0.03 * t, 0), w, h)
+        jobs.append(dict(w=w, h=h, pos=pos, rad=rad, col=col, cam=cam, out=None, err=None))
+
+    def work(job):
+        try:
+            from cudaraytracing_amd.host import DeviceBuffer
+            stream = C.c_void_p()
+            abi.check(lib.rc_stream_create(C.byref(stream)))
+            scene = GpuScene(job["pos"], job["rad"], job["col"])
+            w, h = job["w"], job["h"]
+            surf = DeviceBuffer(w * 16 * h)
+            screen = abi.RcScreen(surf.ptr.value, w, h, w * 16)
+            sc = scene.scene(job["cam"])
+            opts = abi.RcOpts(stream=stream)
+            for _ in range(25):
+                abi.check(lib.rc_render(C.byref(screen), C.byref(sc), C.byref(opts)), "rc_render")
+            abi.check(lib.rc_sync(stream))
+            out = np.empty((h, w, 4), np.float32)
+            abi.check(lib.rc_download_2d(out.ctypes.data_as(C.c_void_p), w * 16, surf.ptr, w * 16, w * 16, h, stream))
+            job["out"] = out
+            surf.free(); scene.free()
+            abi.check(lib.rc_stream_destroy(stream))
+        except Exception as e:           # surfaced in the main thread
+            job["err"] = e
+
+    threads = [threading.Thread(target=work, args=(j,)) for j in jobs]
+    for t in threads:
+        t.start()
+    for t in threads:
+        t.join()
+    for j in jobs:
+        assert j["err"] is None, j["err"]
+        want = oracle.render(j["pos"], j["rad"], j["col"], j["cam"], j["w"], j["h"])
+        assert_same_bits(j["out"], want, f"threaded frame {j['w']}x{j['h']}")
+
+
+def test_bench_contract_line():
+    """bench.py prints ONE JSON line with the fields the driver reads."""
+    import json, sys
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--steps", "5", "--warmup", "2",
+                        "--config", "c2_1920x1080_n64"], capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stderr[-2000:]
+    lines = [l for l in r.stdout.splitlines() if l.strip()]
+    assert len(lines) == 1
+    d = json.loads(lines[0])
+    for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling",
+              "vs_baseline", "dtype", "data", "config", "roofline", "cpu_baseline"):
+        assert k in d, k
+    assert d["n_gpus"] == 1 and d["steps"] == 5 and d["warmup"] == 2 and d["higher_is_better"] is True
+    assert d["unit"] == "Mrays/s" and d["value"] > 0 and d["vs_baseline"] is None
+    assert d["config"]["workload"] == "c2_1920x1080_n64"
+    for k in ("bound", "achieved", "peak", "unit", "frac", "traffic"):
+        assert k in d["roofline"], k
+    for k in ("value", "unit", "cores", "kind", "sample"):
+        assert k in d["cpu_baseline"], k
+    assert d["cpu_baseline"]["kind"] == "port" and d["cpu_baseline"]["cores"] >= 1
+
+
 def test_argument_validation_on_device(rclib):
     screen = abi.RcScreen(None, 64, 64, 1024)
     scene = abi.RcScene()
