@@ -6,7 +6,7 @@
 
 A step is one pass of the hot path (rc_render -> the draw kernel) over one frame of the
 workload, inputs (scene arrays, sine tables) already resident in HBM.  Default workload:
-3840x2160, 1024 spheres, camera (0,0,20) -- the configuration BASELINE.json's metric names.
+3840x2160, 1024 spheres, camera (0,0,20) -- the configuration the headline metric is quoted on.
 
 Multi-GPU (launched by torch.distributed.run, one rank per GPU):
   --mode frames (default)  whole frames are sharded over ranks, no data-path collective;
@@ -215,6 +215,8 @@ def main():
             f = (i * (world if args.mode == "frames" else 1) + (rank if args.mode == "frames" else 0)) % configs.SEQUENCE_FRAMES
             cam.position, cam.rotation = configs.sequence_camera(f)
             scene.cam = cam.get_data()                     # SceneManager::UpdateCamera
+            if rc_ext is not None:
+                rc_ext.light_pos = abi.RcVec3(*configs.sequence_light(f))
         abi.check(lib.rc_render(C.byref(screen), C.byref(scene), C.byref(opts)), "rc_render")
         if args.mode == "bands" and world > 1:
             if comm_device == "cuda":
@@ -248,6 +250,32 @@ def main():
     abi.check(lib.rc_event_elapsed_ms(ev0, ev1, C.byref(ev_ms)))
 
     dt_max = sharding.max_over_ranks(dt, comm_device)
+
+    # Per-frame distribution (median, p10, p90): 100 more frames, each between
+    # its own pair of HIP events, outside the timed region.
+    frame_stats = None
+    if rank == 0 and args.mode == "frames":
+        evs = []
+        for i in range(101):
+            e = C.c_void_p()
+            abi.check(lib.rc_event_create(C.byref(e)))
+            evs.append(e)
+        abi.check(lib.rc_event_record(evs[0], stream))
+        for i in range(100):
+            step(args.warmup + args.steps + i)
+            abi.check(lib.rc_event_record(evs[i + 1], stream))
+        torch.cuda.synchronize()
+        per = []
+        for i in range(100):
+            ms = C.c_float()
+            abi.check(lib.rc_event_elapsed_ms(evs[i], evs[i + 1], C.byref(ms)))
+            per.append(ms.value)
+        for e in evs:
+            lib.rc_event_destroy(e)
+        per.sort()
+        frame_stats = {"frames": 100, "median_ms": per[50], "p10_ms": per[10], "p90_ms": per[90], "min_ms": per[0], "max_ms": per[-1]}
+    if world > 1:
+        dist.barrier()
 
     # Secondary measurement (N=1, default variant only): the opt-in tile-culling variant on the same
     # workload.  It is NOT `value`: it no longer performs one test per (pixel, sphere) pair.
@@ -317,7 +345,7 @@ def main():
                        "variant": args.variant, "sharding": args.mode, "backend": backend if world > 1 else None,
                        "camera": "sequence" if args.sequence else "static",
                        "device": name.value.decode(), "compute_units": cu.value, "clock_mhz": khz.value / 1e3},
-            "frame_ms": kernel_ms,
+            "frame_ms": kernel_ms, "frame_ms_stats": frame_stats,
             "roofline": {
                 "bound": "valu_fp32", "achieved": achieved_tflops, "peak": FP32_VECTOR_PEAK_TFLOPS, "unit": "TFLOP/s",
                 "frac": achieved_tflops / FP32_VECTOR_PEAK_TFLOPS, "traffic": traffic,

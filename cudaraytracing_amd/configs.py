@@ -46,6 +46,13 @@ def sequence_camera(frame, frames=SEQUENCE_FRAMES):
     return f32(pos), f32(rot)
 
 
+def sequence_light(frame, frames=SEQUENCE_FRAMES):
+    """EXT-mode light animation of the sequence: the point light orbits the sphere cloud at height 14,
+    radius 14 (double arithmetic, rounded to float once, like the camera path)."""
+    th = 2.0 * math.pi * frame / frames
+    return tuple(float(np.float32(v)) for v in (14.0 * math.cos(th), 14.0, -10.0 + 22.0 * math.sin(th)))
+
+
 def band_rows(height, world, rank):
     """Row band [begin, end) of `rank` among `world` ranks; band heights differ by <= 1."""
     base, rem = divmod(height, world)

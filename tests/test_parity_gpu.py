@@ -332,7 +332,7 @@ def test_rgba8_fused_and_standalone(oracle):
 @pytest.mark.parametrize("name", ["c3_3840x2160_n1024", "c4_7680x4320_n4096",
                                   "c5_seq_f0", "c5_seq_f37", "c5_seq_f150", "c5_seq_f299"])
 def test_full_size_golden_hashes(oracle, golden, name):
-    """BASELINE-size frames against the oracle's committed hashes; tiled == literal as well."""
+    """Benchmark-size frames against the oracle's committed hashes; tiled == literal as well."""
     if name not in golden:
         pytest.fail(f"{name} missing from tests/golden/golden.json (run make_golden.py --full)")
     fx = golden[name]
