@@ -444,6 +444,10 @@ __device__ __forceinline__ void rc_shadow_pass(const RcKernArgs &a, char *lds,
         if (idx[p] != -1 && (!(ee < 1.0f + 0x1p-19f) || !(ee > 1.0f - 0x1p-19f))) lane_forced = true;
     }
     const unsigned long long forced_mask = __builtin_amdgcn_ballot_w64(lane_forced);
+    bool any_hit = false;
+#pragma unroll
+    for (int p = 0; p < P; p++) any_hit = any_hit || (idx[p] != -1);
+    const bool wave_has_hits = __builtin_amdgcn_ballot_w64(any_hit) != 0ull;   // no hit pixel: no shadow rays
 
     for (int base = 0; base < a.n; base += cap) {
         const int cn = min(a.n - base, cap);
@@ -466,7 +470,7 @@ __device__ __forceinline__ void rc_shadow_pass(const RcKernArgs &a, char *lds,
         }
         __syncthreads();
         const unsigned long long flag0_mask = (*s_has_always != 0) ? ~0ull : forced_mask;
-        const int nblocks = cnb / kBlockSpheres;
+        const int nblocks = wave_has_hits ? cnb / kBlockSpheres : 0;
 
         for (int blk = 0; blk < nblocks; blk++) {
             float m[P];
@@ -742,7 +746,7 @@ __device__ __forceinline__ void rc_tiled_body(const RcKernArgs &a, char *lds)
 } // namespace
 
 template <int P, bool EXT, bool CULL>
-__global__ __launch_bounds__(256) void rc_draw_tiled(RcKernArgs a)
+__global__ __launch_bounds__(256, (EXT && P == 4) ? 4 : 1) void rc_draw_tiled(RcKernArgs a)
 {
     extern __shared__ __attribute__((aligned(16))) char rc_lds[];
     rc_tiled_body<P, EXT, CULL>(a, rc_lds);
