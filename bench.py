@@ -47,6 +47,7 @@ def parse():
     ap.add_argument("--config", default="c3_3840x2160_n1024", choices=sorted(configs.CONFIGS))
     ap.add_argument("--mode", default="frames", choices=["frames", "bands"])
     ap.add_argument("--sequence", action="store_true", help="animate the camera along the 300-frame path")
+    ap.add_argument("--subbands", type=int, default=2, help="bands mode: pieces per band, rendered and sent one after the other")
     ap.add_argument("--variant", default="tiled", choices=["tiled", "tiled2", "tiled4", "tiled8", "culled", "literal"])
     ap.add_argument("--shading", default="ref", choices=["ref", "ext"],
                     help="ref: the reference's math; ext: + plane, point light, Phong, hard shadows (unpinned by the reference)")
@@ -210,6 +211,8 @@ def main():
     if args.mode == "bands" and world > 1 and rank == 0:
         full = torch.empty((h, w, 4), dtype=torch.float32, device="cuda")
 
+    gatherer = sharding.BandGather(h, world, rank, parts=args.subbands) if (args.mode == "bands" and world > 1) else None
+
     def step(i):
         if args.sequence:
             f = (i * (world if args.mode == "frames" else 1) + (rank if args.mode == "frames" else 0)) % configs.SEQUENCE_FRAMES
@@ -217,16 +220,27 @@ def main():
             scene.cam = cam.get_data()                     # SceneManager::UpdateCamera
             if rc_ext is not None:
                 rc_ext.light_pos = abi.RcVec3(*configs.sequence_light(f))
-        abi.check(lib.rc_render(C.byref(screen), C.byref(scene), C.byref(opts)), "rc_render")
-        if args.mode == "bands" and world > 1:
-            if comm_device == "cuda":
-                sharding.gather_bands(frame, full, h, world, rank, dst=0)
-            else:                                   # rehearsal backend: stage through host memory
-                torch.cuda.current_stream().synchronize()
-                host_full = torch.empty((h, w, 4), dtype=torch.float32) if rank == 0 else None
-                sharding.gather_bands(frame.cpu(), host_full, h, world, rank, dst=0)
-                if rank == 0:
-                    full.copy_(host_full)
+        if gatherer is None:
+            abi.check(lib.rc_render(C.byref(screen), C.byref(scene), C.byref(opts)), "rc_render")
+        elif comm_device == "cuda":
+            # render the band piece by piece; each piece is sent while the next one renders
+            gatherer.post_receives(full)
+            for k, (sb, se) in enumerate(gatherer.pieces):
+                if se > sb:
+                    piece = abi.RcScreen(frame[sb - y0:].data_ptr(), w, se - sb, w * 16)
+                    popts = abi.RcOpts.from_buffer_copy(bytes(opts))
+                    popts.ext = opts.ext
+                    popts.y_offset = sb
+                    abi.check(lib.rc_render(C.byref(piece), C.byref(scene), C.byref(popts)), "rc_render")
+                gatherer.piece_rendered(k, frame, full)
+            gatherer.wait()
+        else:                                   # rehearsal backend: stage through host memory
+            abi.check(lib.rc_render(C.byref(screen), C.byref(scene), C.byref(opts)), "rc_render")
+            torch.cuda.current_stream().synchronize()
+            host_full = torch.empty((h, w, 4), dtype=torch.float32) if rank == 0 else None
+            sharding.gather_bands(frame.cpu(), host_full, h, world, rank, dst=0)
+            if rank == 0:
+                full.copy_(host_full)
 
     def fence():
         if world > 1:

@@ -374,13 +374,19 @@ __device__ __forceinline__ void rc_visit_sphere(const RcKernArgs &a, const float
     const float *g = rec + (j >> 2) * 12 + (j & 3);
     const float r = __builtin_fmaf(fb, g[4], g[0]);
     const float be = g[8];
-    bool cand = lane_forced || (flagb[j] != 0);
+    const bool all = lane_forced || (flagb[j] != 0);
+    unsigned long long pm[P], any = 0ull;
 #pragma unroll
-    for (int p = 0; p < P; p++) cand = cand || (__builtin_fmaf(fa[p], be, r) >= len[p]);
-    if (__builtin_amdgcn_ballot_w64(cand) == 0ull) return;
+    for (int p = 0; p < P; p++) {
+        pm[p] = __builtin_amdgcn_ballot_w64(all || (__builtin_fmaf(fa[p], be, r) >= len[p]));
+        any |= pm[p];
+    }
+    if (any == 0ull) return;
     const RcExactSphere e = rc_exact_sphere(a, base + j);
+    // the exact test only for pixel columns in which some lane still flags the sphere
 #pragma unroll
-    for (int p = 0; p < P; p++) rc_exact_test(e, dx[p], dy[p], dz[p], base + j, minDist[p], idx[p]);
+    for (int p = 0; p < P; p++)
+        if (pm[p] != 0ull) rc_exact_test(e, dx[p], dy[p], dz[p], base + j, minDist[p], idx[p]);
 }
 
 __device__ __forceinline__ float rc_wave_min(float v)

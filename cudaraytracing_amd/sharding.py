@@ -50,6 +50,68 @@ def gather_bands(band, full, height, world, rank, dst=0):
             req.wait()
 
 
+def sub_bands(begin, end, parts):
+    """Split rows [begin, end) into `parts` nearly equal sub-bands (for render/transfer overlap)."""
+    rows = end - begin
+    parts = max(1, min(parts, rows)) if rows > 0 else 1
+    base, rem = divmod(rows, parts)
+    out, b = [], begin
+    for i in range(parts):
+        e = b + base + (1 if i < rem else 0)
+        out.append((b, e))
+        b = e
+    return out
+
+
+class BandGather:
+    """Row-band gather with render/transfer overlap.
+
+    A rank's band is rendered in `parts` sub-bands; the transfer of sub-band k is posted as soon
+    as its render has been enqueued, so it travels while sub-band k+1 renders (the collective
+    library orders each transfer after the work already enqueued on the current stream).  The
+    root posts all its receives first, straight into the rows of the full frame.
+    """
+
+    def __init__(self, height, world, rank, parts=2, dst=0):
+        self.height, self.world, self.rank, self.parts, self.dst = height, world, rank, parts, dst
+        self.begin, self.end = band_rows(height, world, rank)
+        self.pieces = sub_bands(self.begin, self.end, parts)
+        self._reqs = []
+
+    def post_receives(self, full):
+        """Root only: one receive per peer sub-band, into full[rows]."""
+        if self.rank != self.dst or self.world == 1:
+            return
+        ops = []
+        for r in range(self.world):
+            if r == self.dst:
+                continue
+            b, e = band_rows(self.height, self.world, r)
+            for sb, se in sub_bands(b, e, self.parts):
+                if se > sb:
+                    ops.append(dist.P2POp(dist.irecv, full[sb:se], r))
+        if ops:
+            self._reqs += dist.batch_isend_irecv(ops)
+
+    def piece_rendered(self, k, band, full=None):
+        """Call right after sub-band k of this rank's band has been enqueued for rendering.
+        band: this rank's [rows, width, 4] tensor."""
+        sb, se = self.pieces[k]
+        if se <= sb:
+            return
+        view = band[sb - self.begin: se - self.begin]
+        if self.world == 1 or self.rank == self.dst:
+            if full is not None:
+                full[sb:se].copy_(view, non_blocking=True)
+        else:
+            self._reqs += dist.batch_isend_irecv([dist.P2POp(dist.isend, view, self.dst)])
+
+    def wait(self):
+        for r in self._reqs:
+            r.wait()
+        self._reqs = []
+
+
 def max_over_ranks(value, device):
     """MAX of a python float over all ranks (used for the timed region of bench.py)."""
     t = torch.tensor([value], dtype=torch.float64, device=device)

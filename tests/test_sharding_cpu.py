@@ -43,6 +43,51 @@ def _worker(rank, world, port, w, h, n, out_path):
         dist.destroy_process_group()
 
 
+def _worker_overlap(rank, world, port, w, h, n, parts, out_path):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        from oracle import binding as ob
+        pos, rad, col = ob.generate_scene(n, 0)
+        cam = ob.camera_data((0, 0, 20), (0.05, -0.1, 0), w, h)
+        g = sharding.BandGather(h, world, rank, parts=parts, dst=0)
+        full = torch.zeros((h, w, 4), dtype=torch.float32) if rank == 0 else None
+        band = torch.zeros((g.end - g.begin, w, 4), dtype=torch.float32)
+        g.post_receives(full)
+        for k, (sb, se) in enumerate(g.pieces):
+            if se > sb:
+                piece = ob.render(pos, rad, col, cam, w, se - sb, y_offset=sb, full_height=h, threads=2)
+                band[sb - g.begin: se - g.begin] = torch.from_numpy(piece)
+            g.piece_rendered(k, band, full)
+        g.wait()
+        dist.barrier()
+        if rank == 0:
+            np.save(out_path, full.numpy())
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("world,h,parts", [(2, 96, 2), (3, 101, 3), (2, 5, 4)])
+def test_band_gather_with_overlap_pieces_gloo(oracle, tmp_path, world, h, parts):
+    w, n = 96, 30
+    out = str(tmp_path / "full.npy")
+    mp.spawn(_worker_overlap, args=(world, _free_port(), w, h, n, parts, out), nprocs=world, join=True)
+    got = np.load(out)
+    pos, rad, col = oracle.generate_scene(n, 0)
+    cam = oracle.camera_data((0, 0, 20), (0.05, -0.1, 0), w, h)
+    want = oracle.render(pos, rad, col, cam, w, h)
+    assert np.array_equal(got.view(np.uint32), want.view(np.uint32))
+
+
+def test_sub_bands_partition():
+    for b, e, parts in [(0, 10, 3), (5, 6, 4), (7, 7, 2), (100, 640, 2)]:
+        sp = sharding.sub_bands(b, e, parts)
+        assert sp[0][0] == b and sp[-1][1] == e
+        for x, y in zip(sp, sp[1:]):
+            assert x[1] == y[0]
+
+
 @pytest.mark.parametrize("world,h", [(2, 96), (3, 100)])
 def test_band_gather_gloo(oracle, tmp_path, world, h):
     w, n = 128, 40
