@@ -64,6 +64,7 @@ assert C.sizeof(RcScene) == 88 and C.sizeof(RcScreen) == 24 and C.sizeof(RcExt) 
 # every symbol include/rc_abi.h declares: name -> (restype, argtypes)
 SYMBOLS = {
     "rc_render": (C.c_int, [C.POINTER(RcScreen), C.POINTER(RcScene), C.POINTER(RcOpts)]),
+    "rc_prepare": (C.c_int, [C.c_int, C.c_int, C.c_float]),
     "rc_to_rgba8": (C.c_int, [C.POINTER(RcScreen), C.c_void_p, C.c_size_t, C.c_int, C.c_void_p]),
     "rc_device_count": (C.c_int, [C.POINTER(C.c_int)]),
     "rc_device_name": (C.c_int, [C.c_int, C.c_char_p, C.c_size_t]),

@@ -236,6 +236,13 @@ extern "C" int rc_render(const rc_screen *screen, const rc_scene *scene, const r
     return RC_OK;
 }
 
+extern "C" int rc_prepare(int width, int full_height, float fov)
+{
+    if (width <= 0 || full_height <= 0) return rc_fail_arg("width/full_height must be positive");
+    const float *sx = nullptr, *sy = nullptr;
+    return rc_get_tables(fov, width, full_height, &sx, &sy);
+}
+
 extern "C" int rc_to_rgba8(const rc_screen *screen, void *rgba8, size_t rgba8_pitch, int flip, void *stream)
 {
     if (!screen || !screen->surface || !rgba8) return rc_fail_arg("null pointer");

@@ -126,6 +126,12 @@ typedef struct rc_opts {
  * floor-divided grid at kernel.cu:121 drops the remainder rows/columns).  Enqueue only. */
 int rc_render(const rc_screen *screen, const rc_scene *scene, const rc_opts *opts);
 
+/* Builds, for the current device, the cached sine tables rc_render needs for frames of this
+ * width / full height / field of view (kernel.cu:46-47), so that later rc_render calls with the
+ * same three values allocate and copy nothing (e.g. before capturing them into a HIP graph).
+ * No counterpart in the reference, which evaluates sinf per pixel on the device. */
+int rc_prepare(int width, int full_height, float fov);
+
 /* Display step after the path (DXManager.cpp:134,299,328: the float texture drawn 1:1 into
  * an R8G8B8A8_UNORM target): NaN->0, clamp [0,1], *255 + 0.5, truncate.  Device to device. */
 int rc_to_rgba8(const rc_screen *screen, void *rgba8, size_t rgba8_pitch, int flip, void *stream);

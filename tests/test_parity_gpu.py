@@ -486,6 +486,16 @@ def test_bench_contract_line():
     assert d["cpu_baseline"]["kind"] == "port" and d["cpu_baseline"]["cores"] >= 1
 
 
+def test_prepare_then_render(oracle, rclib):
+    w, h, n = 250, 130, 20
+    cam = oracle.camera_data((0, 0, 20), (0, 0, 0), w, h)
+    assert rclib.rc_prepare(w, h, cam.fov) == 0
+    assert rclib.rc_prepare(0, h, cam.fov) == abi.RC_EINVAL
+    pos, rad, col = oracle.generate_scene(n, 8)
+    got = pixels(gpu_render(pos, rad, col, cam, w, h), w)
+    assert_same_bits(got, oracle.render(pos, rad, col, cam, w, h), "after rc_prepare")
+
+
 def test_argument_validation_on_device(rclib):
     screen = abi.RcScreen(None, 64, 64, 1024)
     scene = abi.RcScene()
