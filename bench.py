@@ -167,7 +167,10 @@ def main():
     torch.cuda.set_device(local_rank)
     lib = abi.load()
     abi.check(lib.rc_set_device(local_rank), "rc_set_device")
-    if world > 1:
+    # a process group also for one rank when launched through torch.distributed.run
+    # (exercises the RCCL set-up, barrier and MAX reduction on a one-GPU box)
+    use_dist = world > 1 or ("RANK" in os.environ and "MASTER_ADDR" in os.environ)
+    if use_dist:
         if backend == "nccl":
             dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
         else:
@@ -243,7 +246,7 @@ def main():
                 full.copy_(host_full)
 
     def fence():
-        if world > 1:
+        if use_dist:
             dist.barrier()
         torch.cuda.synchronize()
 
@@ -288,7 +291,7 @@ def main():
             lib.rc_event_destroy(e)
         per.sort()
         frame_stats = {"frames": 100, "median_ms": per[50], "p10_ms": per[10], "p90_ms": per[90], "min_ms": per[0], "max_ms": per[-1]}
-    if world > 1:
+    if use_dist:
         dist.barrier()
 
     # Secondary measurement (N=1, default variant only): the opt-in tile-culling variant on the same
@@ -391,7 +394,7 @@ def main():
             out["cpu_baseline"] = None
         print(json.dumps(out), flush=True)
 
-    if world > 1:
+    if use_dist:
         dist.destroy_process_group()
 
 

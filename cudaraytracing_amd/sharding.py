@@ -79,19 +79,21 @@ class BandGather:
         self._reqs = []
 
     def post_receives(self, full):
-        """Root only: one receive per peer sub-band, into full[rows]."""
+        """Root only: one receive per peer sub-band, into full[rows].  One batch per piece
+        index, so the root's groups mirror the peers' (each peer sends piece k as group k)."""
         if self.rank != self.dst or self.world == 1:
             return
-        ops = []
-        for r in range(self.world):
-            if r == self.dst:
-                continue
-            b, e = band_rows(self.height, self.world, r)
-            for sb, se in sub_bands(b, e, self.parts):
-                if se > sb:
-                    ops.append(dist.P2POp(dist.irecv, full[sb:se], r))
-        if ops:
-            self._reqs += dist.batch_isend_irecv(ops)
+        for k in range(self.parts):
+            ops = []
+            for r in range(self.world):
+                if r == self.dst:
+                    continue
+                b, e = band_rows(self.height, self.world, r)
+                pieces = sub_bands(b, e, self.parts)
+                if k < len(pieces) and pieces[k][1] > pieces[k][0]:
+                    ops.append(dist.P2POp(dist.irecv, full[pieces[k][0]:pieces[k][1]], r))
+            if ops:
+                self._reqs += dist.batch_isend_irecv(ops)
 
     def piece_rendered(self, k, band, full=None):
         """Call right after sub-band k of this rank's band has been enqueued for rendering.
@@ -115,6 +117,6 @@ class BandGather:
 def max_over_ranks(value, device):
     """MAX of a python float over all ranks (used for the timed region of bench.py)."""
     t = torch.tensor([value], dtype=torch.float64, device=device)
-    if dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1:
+    if dist.is_available() and dist.is_initialized():
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
     return float(t.item())
