@@ -11,6 +11,7 @@
 #include <string.h>
 
 #include <mutex>
+#include <shared_mutex>
 #include <random>
 #include <vector>
 
@@ -32,6 +33,7 @@ static_assert(offsetof(rc_screen, width) == 8 && offsetof(rc_screen, height) == 
 namespace {
 
 thread_local char g_err[256] = "";
+constexpr int kMaxDim = 65536;      // frame width / height limit (keeps every grid within range)
 
 int rc_fail_hip(hipError_t e, const char *what)
 {
@@ -53,7 +55,9 @@ int rc_fail_arg(const char *what)
 
 // ---- sine tables (kernel.cu:46-49) ---------------------------------------------------
 // sin_x[x] = sinf(fov * (1.0f * x / width - 0.5f)), sin_y likewise over full_height.
-// Entries are immutable once built, so frames in flight on any stream keep valid tables.
+// Entries are immutable once built.  A render holds the cache's shared lock from the lookup
+// until its kernel is enqueued; building and evicting take the exclusive lock, and eviction
+// waits for the device before freeing, so no frame ever reads a freed table.
 struct SinTables {
     int device;
     uint32_t fov_bits;
@@ -62,31 +66,34 @@ struct SinTables {
     uint64_t last_use;
 };
 
-std::mutex g_mu;
+std::shared_mutex g_mu;
 std::vector<SinTables> g_tables;
 uint64_t g_tick = 0;
 constexpr size_t kMaxTables = 32;   // per device
 
-int rc_get_tables(float fov, int width, int full_height, const float **sx, const float **sy)
+// caller holds g_mu (shared or exclusive)
+bool rc_find_tables(int dev, uint32_t fb, int width, int full_height, const float **sx, const float **sy)
 {
-    int dev = 0;
-    RC_HIP(hipGetDevice(&dev));
-    uint32_t fb;
-    memcpy(&fb, &fov, 4);
-    std::lock_guard<std::mutex> lock(g_mu);
     for (auto &t : g_tables) {
         if (t.device == dev && t.fov_bits == fb && t.width == width && t.full_height == full_height) {
-            t.last_use = ++g_tick;
+            __atomic_store_n(&t.last_use, __atomic_add_fetch(&g_tick, 1, __ATOMIC_RELAXED), __ATOMIC_RELAXED);
             *sx = t.d_base;
             *sy = t.d_base + width;
-            return RC_OK;
+            return true;
         }
     }
+    return false;
+}
+
+// caller holds g_mu exclusively
+int rc_build_tables(int dev, uint32_t fb, float fov, int width, int full_height)
+{
+    const float *sx, *sy;
+    if (rc_find_tables(dev, fb, width, full_height, &sx, &sy)) return RC_OK;   // another thread was first
     size_t mine = 0;
     for (const auto &t : g_tables) mine += (t.device == dev);
     if (mine >= kMaxTables) {
-        // evict this device's least recently used entry; frames that still read it must have
-        // finished first
+        // evict this device's least recently used entry once the frames that read it have finished
         size_t victim = g_tables.size();
         for (size_t i = 0; i < g_tables.size(); i++)
             if (g_tables[i].device == dev && (victim == g_tables.size() || g_tables[i].last_use < g_tables[victim].last_use))
@@ -108,9 +115,28 @@ int rc_get_tables(float fov, int width, int full_height, const float **sx, const
         return rc_fail_hip(e, "hipMemcpy(sin tables)");
     }
     g_tables.push_back(t);
-    *sx = t.d_base;
-    *sy = t.d_base + width;
     return RC_OK;
+}
+
+// Looks the tables up, building them first if needed.  On success `lease` holds the shared
+// lock: the caller releases it after the kernel that reads the tables has been enqueued.
+int rc_get_tables(float fov, int width, int full_height, const float **sx, const float **sy,
+                  std::shared_lock<std::shared_mutex> &lease)
+{
+    int dev = 0;
+    RC_HIP(hipGetDevice(&dev));
+    uint32_t fb;
+    memcpy(&fb, &fov, 4);
+    for (int attempt = 0; attempt < 8; attempt++) {
+        lease = std::shared_lock<std::shared_mutex>(g_mu);
+        if (rc_find_tables(dev, fb, width, full_height, sx, sy)) return RC_OK;
+        lease.unlock();
+        std::unique_lock<std::shared_mutex> build(g_mu);
+        int rc = rc_build_tables(dev, fb, fov, width, full_height);
+        if (rc != RC_OK) return rc;
+    }
+    snprintf(g_err, sizeof(g_err), "sine table cache thrashing: more than %zu frame formats in use at once", kMaxTables);
+    return RC_EINVAL;
 }
 
 // compute units per device, queried once (sizes the tiled kernel's grid)
@@ -139,6 +165,8 @@ extern "C" int rc_render(const rc_screen *screen, const rc_scene *scene, const r
     if (!screen || !scene) return rc_fail_arg("null screen or scene");
     if (!screen->surface) return rc_fail_arg("null surface");
     if (screen->width <= 0 || screen->height <= 0) return rc_fail_arg("width/height must be positive");
+    if (screen->width > kMaxDim || screen->height > kMaxDim || (opts && opts->full_height > kMaxDim))
+        return rc_fail_arg("width/height/full_height above 65536");
     if (screen->pitch < (size_t)screen->width * 16 || (screen->pitch & 15) != 0)
         return rc_fail_arg("pitch must be >= 16*width and a multiple of 16");
     if ((reinterpret_cast<uintptr_t>(screen->surface) & 15) != 0) return rc_fail_arg("surface must be 16-byte aligned");
@@ -175,7 +203,8 @@ extern "C" int rc_render(const rc_screen *screen, const rc_scene *scene, const r
     }
 
     const float *sx = nullptr, *sy = nullptr;
-    int rc = rc_get_tables(scene->cam.fov, screen->width, full_height, &sx, &sy);
+    std::shared_lock<std::shared_mutex> lease;     // held until the kernel is enqueued
+    int rc = rc_get_tables(scene->cam.fov, screen->width, full_height, &sx, &sy, lease);
     if (rc != RC_OK) return rc;
 
     RcKernArgs a;
@@ -239,8 +268,10 @@ extern "C" int rc_render(const rc_screen *screen, const rc_scene *scene, const r
 extern "C" int rc_prepare(int width, int full_height, float fov)
 {
     if (width <= 0 || full_height <= 0) return rc_fail_arg("width/full_height must be positive");
+    if (width > kMaxDim || full_height > kMaxDim) return rc_fail_arg("width/full_height above 65536");
     const float *sx = nullptr, *sy = nullptr;
-    return rc_get_tables(fov, width, full_height, &sx, &sy);
+    std::shared_lock<std::shared_mutex> lease;
+    return rc_get_tables(fov, width, full_height, &sx, &sy, lease);
 }
 
 extern "C" int rc_to_rgba8(const rc_screen *screen, void *rgba8, size_t rgba8_pitch, int flip, void *stream)
@@ -249,6 +280,9 @@ extern "C" int rc_to_rgba8(const rc_screen *screen, void *rgba8, size_t rgba8_pi
     if (screen->width <= 0 || screen->height <= 0) return rc_fail_arg("width/height must be positive");
     if (screen->pitch < (size_t)screen->width * 16 || (screen->pitch & 15) != 0) return rc_fail_arg("bad surface pitch");
     if (rgba8_pitch < (size_t)screen->width * 4 || (rgba8_pitch & 3) != 0) return rc_fail_arg("bad rgba8 pitch");
+    if ((reinterpret_cast<uintptr_t>(screen->surface) & 15) != 0 || (reinterpret_cast<uintptr_t>(rgba8) & 3) != 0)
+        return rc_fail_arg("surface must be 16-byte and rgba8 4-byte aligned");
+    if (screen->width > kMaxDim || screen->height > kMaxDim) return rc_fail_arg("width/height above 65536");
     hipError_t e = rc_launch_rgba8(screen->surface, screen->pitch, screen->width, screen->height, rgba8,
                                    rgba8_pitch, flip, static_cast<hipStream_t>(stream));
     if (e != hipSuccess) return rc_fail_hip(e, "rgba8 kernel launch");
@@ -505,9 +539,16 @@ extern "C" int rc_write_ppm(const char *path, const uint8_t *rgba8, size_t pitch
             line[3 * (size_t)x + 1] = src[4 * (size_t)x + 1];
             line[3 * (size_t)x + 2] = src[4 * (size_t)x + 2];
         }
-        fwrite(line.data(), 1, line.size(), f);
+        if (fwrite(line.data(), 1, line.size(), f) != line.size()) {
+            fclose(f);
+            snprintf(g_err, sizeof(g_err), "short write to %s", path);
+            return RC_EINVAL;
+        }
     }
-    fclose(f);
+    if (fclose(f) != 0) {
+        snprintf(g_err, sizeof(g_err), "cannot finish writing %s", path);
+        return RC_EINVAL;
+    }
     return RC_OK;
 }
 

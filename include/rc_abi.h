@@ -123,7 +123,8 @@ typedef struct rc_opts {
 
 /* Replaces execute_kernel (kernel.cu:114-131, declared by hand at RayTracingKernel.cpp:3-6,
  * called at RayTracingKernel.cpp:17).  Renders EVERY pixel of the screen (the reference's
- * floor-divided grid at kernel.cu:121 drops the remainder rows/columns).  Enqueue only. */
+ * floor-divided grid at kernel.cu:121 drops the remainder rows/columns).  Enqueue only.
+ * Width, height and full_height may be at most 65536; sphere_num is unlimited. */
 int rc_render(const rc_screen *screen, const rc_scene *scene, const rc_opts *opts);
 
 /* Builds, for the current device, the cached sine tables rc_render needs for frames of this

@@ -501,3 +501,27 @@ def test_argument_validation_on_device(rclib):
     scene = abi.RcScene()
     assert rclib.rc_render(C.byref(screen), C.byref(scene), None) == abi.RC_EINVAL
     assert b"surface" in rclib.rc_last_error_string()
+
+
+def test_sine_table_cache_eviction(oracle, rclib):
+    """More frame formats than the per-device table cache holds (32): old tables are evicted and
+    rebuilt on demand; the first and the last formats still render bit-exactly afterwards."""
+    n = 12
+    pos, rad, col = oracle.generate_scene(n, 21)
+    scene = GpuScene(pos, rad, col)
+    formats = [(40 + 3 * i, 24 + i) for i in range(40)]
+    for rnd in range(2):
+        for i, (w, h) in enumerate(formats):
+            cam = oracle.camera_data((0, 0, 20), (0, 0, 0), w, h)
+            got = pixels(gpu_render(None, None, None, cam, w, h, scene=scene), w)
+            if i in (0, 1, 38, 39):
+                assert_same_bits(got, oracle.render(pos, rad, col, cam, w, h), f"round {rnd} format {w}x{h}")
+    scene.free()
+
+
+def test_frame_size_limit(rclib):
+    scene = abi.RcScene()
+    screen = abi.RcScreen(16, 65537, 4, 65537 * 16)
+    assert rclib.rc_render(C.byref(screen), C.byref(scene), None) == abi.RC_EINVAL
+    assert b"65536" in rclib.rc_last_error_string()
+    assert rclib.rc_prepare(70000, 4, 0.5) == abi.RC_EINVAL
