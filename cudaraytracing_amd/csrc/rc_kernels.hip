@@ -784,7 +784,7 @@ static long long rc_tile_count(const RcKernArgs &a)
 template <int P>
 static hipError_t rc_launch_tiled(RcKernArgs a, hipStream_t stream)
 {
-    // LDS chunk: the whole scene when it fits (rounded up to whole 16-sphere blocks)
+    // LDS chunk: the whole scene when it fits (rounded up to whole blocks of kBlockSpheres)
     const int n16 = ((a.n > 0 ? a.n : 1) + kBlockSpheres - 1) & ~(kBlockSpheres - 1);
     a.lds_cap = n16 < RC_LDS_CHUNK_MAX ? n16 : RC_LDS_CHUNK_MAX;
     a.tiles_x = (a.width + 16 * P - 1) / (16 * P);

@@ -158,7 +158,7 @@ def test_filter_soak_tiled_vs_literal_on_device(oracle):
     the GPU (the literal kernel is itself held to the oracle above).  Cameras are placed at
     random distances from a random sphere's surface, down to 1e-7 relative, to stress the
     hand-over between the filter and the exact path."""
-    rng = np.random.default_rng(99)
+    rng = np.random.default_rng(int(os.environ.get("RC_SOAK_SEED", "99")))
     w, h = 192, 104
     variants = [abi.VARIANT_TILED2, abi.VARIANT_TILED4, abi.VARIANT_TILED8, abi.VARIANT_CULLED]
     for it in range(int(os.environ.get("RC_SOAK_SCENES", "600"))):
@@ -182,6 +182,8 @@ def test_filter_soak_tiled_vs_literal_on_device(oracle):
         got = pixels(gpu_render(pos, rad, col, cam, w, h, variant=variants[it % 4], scene=scene), w)
         scene.free()
         assert_same_bits(got, want, f"soak {it}: n={n} cam={cpos} rot={rot} variant={variants[it % 4]}")
+        if it % 5000 == 4999:
+            print(f"soak: {it + 1} scenes identical", flush=True)      # progress for long runs (pytest -s)
 
 
 @pytest.mark.parametrize("scale", [1e-12, 1e-6, 1e-3, 1e3, 1e6, 1e12, 1e18])
