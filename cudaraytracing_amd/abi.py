@@ -54,6 +54,13 @@ class RcOpts(C.Structure):
                 ("ext", C.POINTER(RcExt))]
 
 
+class RcInput(C.Structure):
+    """One poll of the interactive controls, scripted (main.cpp:53-128)."""
+    _fields_ = [("rbutton", C.c_int), ("lshift", C.c_int), ("key_q", C.c_int), ("key_z", C.c_int),
+                ("key_w", C.c_int), ("key_a", C.c_int), ("key_s", C.c_int), ("key_d", C.c_int),
+                ("cursor_dx", C.c_int), ("cursor_dy", C.c_int)]
+
+
 MODE_REF = 0
 MODE_EXT = 1
 
@@ -88,6 +95,7 @@ SYMBOLS = {
     "rc_event_elapsed_ms": (C.c_int, [C.c_void_p, C.c_void_p, C.POINTER(C.c_float)]),
     "rc_event_destroy": (C.c_int, [C.c_void_p]),
     "rc_camera_data": (None, [C.POINTER(RcVec3), C.POINTER(RcVec3), C.c_int, C.c_int, C.POINTER(RcCamera)]),
+    "rc_handle_input": (C.c_int, [C.POINTER(RcVec3), C.POINTER(RcVec3), C.c_float, C.c_float, C.c_float, C.POINTER(RcInput)]),
     "rc_generate_scene": (None, [C.c_uint32, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p]),
     "rc_write_ppm": (C.c_int, [C.c_char_p, C.c_void_p, C.c_size_t, C.c_int, C.c_int]),
     "rc_last_error_string": (C.c_char_p, []),

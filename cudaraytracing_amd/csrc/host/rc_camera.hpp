@@ -31,8 +31,15 @@ public:
     rc_vec3 GetUp() const { return GetData().up; }
     rc_vec3 GetRight() const { return GetData().right; }
 
-    // One step of the interactive controls (main.cpp:53-128), scripted: move along the
-    // camera axes by `amount` world units / rotate by radians.
+    // One poll of the interactive controls (main.cpp:53-128) from a scripted input state, in
+    // the reference's arithmetic; dt in milliseconds (main.cpp:137).  True if the camera
+    // changed (the caller then runs SceneManager::UpdateCamera, main.cpp:126-127).
+    bool HandleInput(const rc_input &in, float dt)
+    {
+        return rc_handle_input(&position, &rotation, movement_speed, rotation_speed, dt, &in) == 1;
+    }
+
+    // Free-form scripted moves: along the camera axes by world units / rotate by radians.
     void Move(float forward, float right, float up)
     {
         const rc_camera d = GetData();

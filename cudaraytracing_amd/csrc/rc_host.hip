@@ -504,6 +504,48 @@ extern "C" void rc_camera_data(const rc_vec3 *position, const rc_vec3 *rotation,
     out->right = rc_norm3(c);                               // Camera.h:89-91
 }
 
+// main.cpp:53-128.  The camera axes are those of Camera::GetForward / GetRight
+// (Camera.h:71-91) for the rotation AFTER the mouse-look update, as SetRotation invalidates
+// the cached basis (Camera.h:95-99) before the movement keys read it.
+extern "C" int rc_handle_input(rc_vec3 *position, rc_vec3 *rotation, float movement_speed, float rotation_speed,
+                               float dt, const rc_input *input)
+{
+    if (!position || !rotation || !input) return rc_fail_arg("rc_handle_input: null pointer");
+    int update = 0;
+    if (input->rbutton) {                                      // main.cpp:64-70
+        const float angle = dt * rotation_speed;
+        rotation->x = rotation->x + -(float)input->cursor_dy * angle;
+        rotation->y = rotation->y + -(float)input->cursor_dx * angle;
+        rotation->z = rotation->z + 0.0f;
+        update = 1;
+    }
+    float speed = movement_speed;                              // main.cpp:73-80
+    if (input->lshift) speed *= 5;
+    else speed *= 50;
+
+    if (input->key_q) { position->y += dt * speed; update = 1; }   // main.cpp:82-86
+    if (input->key_z) { position->y -= dt * speed; update = 1; }   // main.cpp:88-92
+
+    rc_camera basis;
+    const rc_vec3 origin = {0.0f, 0.0f, 0.0f};
+    rc_camera_data(&origin, rotation, 1, 1, &basis);           // forward / right for this rotation
+    // norm(axis with y = 0) * speed * dt, each product rounded on its own (vec3.h:126-129,168-171)
+    auto step = [&](rc_vec3 axis, float sign) {
+        axis.y = 0;
+        rc_vec3 m = rc_norm3(axis);
+        m.x *= speed; m.y *= speed; m.z *= speed;
+        m.x *= dt; m.y *= dt; m.z *= dt;
+        if (sign > 0) { position->x += m.x; position->y += m.y; position->z += m.z; }
+        else { position->x -= m.x; position->y -= m.y; position->z -= m.z; }
+        update = 1;
+    };
+    if (input->key_w) step(basis.forward, +1.0f);              // main.cpp:94-100
+    if (input->key_a) step(basis.right, -1.0f);                // main.cpp:102-108
+    if (input->key_s) step(basis.forward, -1.0f);              // main.cpp:110-116
+    if (input->key_d) step(basis.right, +1.0f);                // main.cpp:118-124
+    return update;
+}
+
 extern "C" void rc_generate_scene(uint32_t seed, int n, rc_vec3 *position, float *radius, rc_vec3 *color)
 {
     std::mt19937 gen{seed};                                 // SceneManager.h:22

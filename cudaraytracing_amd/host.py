@@ -49,6 +49,8 @@ class Camera:
         self.width, self.height = int(width), int(height)
         self.position = (0.0, 0.0, 0.0)
         self.rotation = (0.0, 0.0, 0.0)
+        self.movement_speed = 100.0      # Camera.h:48
+        self.rotation_speed = 10.0       # Camera.h:49
 
     def get_data(self):
         lib = abi.load()
@@ -56,6 +58,27 @@ class Camera:
         p, r = RcVec3(*self.position), RcVec3(*self.rotation)
         lib.rc_camera_data(C.byref(p), C.byref(r), self.width, self.height, C.byref(out))
         return out
+
+    def handle_input(self, dt_ms, keys="", cursor=(0, 0)):
+        """One poll of the reference's HandleInput (main.cpp:53-128), scripted.  keys: any of
+        'r' (right mouse button), 'shift', 'q', 'z', 'w', 'a', 's', 'd' separated by spaces;
+        cursor: (dx, dy) since the previous poll; dt_ms: frame time in milliseconds as at
+        main.cpp:137.  Returns True if the camera changed (the caller then updates the scene's
+        CameraData, main.cpp:126-127)."""
+        lib = abi.load()
+        held = set(keys.split())
+        unknown = held - {"r", "shift", "q", "z", "w", "a", "s", "d"}
+        if unknown:
+            raise ValueError(f"unknown keys {sorted(unknown)}")
+        inp = abi.RcInput(rbutton="r" in held, lshift="shift" in held, key_q="q" in held, key_z="z" in held,
+                          key_w="w" in held, key_a="a" in held, key_s="s" in held, key_d="d" in held,
+                          cursor_dx=int(cursor[0]), cursor_dy=int(cursor[1]))
+        p, r = RcVec3(*self.position), RcVec3(*self.rotation)
+        rc = lib.rc_handle_input(C.byref(p), C.byref(r), self.movement_speed, self.rotation_speed, dt_ms, C.byref(inp))
+        if rc < 0:
+            check(rc, "rc_handle_input")
+        self.position, self.rotation = (p.x, p.y, p.z), (r.x, r.y, r.z)
+        return rc == 1
 
 
 def generate_scene(n, seed=0):

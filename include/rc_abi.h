@@ -188,6 +188,24 @@ int rc_event_destroy(void *event);
 void rc_camera_data(const rc_vec3 *position, const rc_vec3 *rotation, int width, int height,
                     rc_camera *out);
 
+/* One poll of the interactive controls, scripted (main.cpp:53-128 reads the same state from
+ * GetKeyState/GetCursorPos).  Non-zero = held down. */
+typedef struct rc_input {
+    int rbutton;             /* VK_RBUTTON: mouse look (main.cpp:64)                          */
+    int lshift;              /* VK_LSHIFT: speed x5 instead of x50 (main.cpp:75-80)           */
+    int key_q, key_z;        /* up / down along world y (main.cpp:82-92)                      */
+    int key_w, key_a, key_s, key_d; /* forward / left / back / right in the xz plane (:94-124) */
+    int cursor_dx, cursor_dy;/* cursor movement since the previous poll (main.cpp:67,71)      */
+} rc_input;
+
+/* main.cpp:53-128 HandleInput: applies one poll to a camera's position and Euler rotation, in
+ * the reference's order and arithmetic (rotation first, then q, z, w, a, s, d; every move is
+ * norm(axis with y = 0) * speed * dt).  dt is the frame time in MILLISECONDS, as the reference
+ * passes it (main.cpp:137).  Returns 1 if the camera changed (the reference then calls
+ * SceneManager::UpdateCamera, main.cpp:126-127), 0 if not, RC_EINVAL for a null pointer. */
+int rc_handle_input(rc_vec3 *position, rc_vec3 *rotation, float movement_speed, float rotation_speed,
+                    float dt, const rc_input *input);
+
 /* SceneManager.cpp:14-15,31-46 with a portable float mapping: std::mt19937(seed)
  * (SceneManager.h:22), u = (r >> 8) * 2^-24, value = lo + u * (hi - lo); per sphere
  * radius [0.3,1], colour [0,1]^3, x [-10,10], y [-5,5], z [-15,-5].  HOST arrays. */

@@ -527,3 +527,33 @@ def test_frame_size_limit(rclib):
     assert rclib.rc_render(C.byref(screen), C.byref(scene), None) == abi.RC_EINVAL
     assert b"65536" in rclib.rc_last_error_string()
     assert rclib.rc_prepare(70000, 4, 0.5) == abi.RC_EINVAL
+
+
+def test_cli_input_script_replay(oracle, tmp_path):
+    """rc_render --script: the reference's interactive controls (main.cpp:53-128) replayed from a
+    file; the last frame equals the oracle's frame for the camera the same polls produce."""
+    from cudaraytracing_amd.host import Camera
+    exe = os.path.join(ROOT, "cudaraytracing_amd", "rc_render")
+    w, h, n = 320, 192, 48
+    polls = [(0.0004, "w", 0, 0), (0.0003, "d+shift", 0, 0), (0.01, "r", 2, -1), (0.0002, "s+q", 0, 0),
+             (0.004, "r+a", -3, 2), (0.0005, "-", 5, 5), (0.0002, "z+w", 0, 0)]
+    script = tmp_path / "input.txt"
+    script.write_text("# dt_ms keys dx dy\n" + "".join(f"{dt!r} {k} {dx} {dy}\n" for dt, k, dx, dy in polls))
+    out = tmp_path / "last.ppm"
+    r = subprocess.run([exe, "--width", str(w), "--height", str(h), "--spheres", str(n), "--script", str(script),
+                        "--out", str(out)], capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, r.stdout + r.stderr
+    assert r.stdout.count("frame: ") == len(polls)
+    cam = Camera(w, h)
+    cam.position = (0.0, 0.0, 20.0)
+    for dt, k, dx, dy in polls:
+        cam.handle_input(np.float32(dt).item(), "" if k == "-" else k.replace("+", " "), (dx, dy))
+    assert cam.position != (0.0, 0.0, 20.0) and cam.rotation != (0.0, 0.0, 0.0)
+    pos, rad, col = oracle.generate_scene(n, 0)
+    ocam = oracle.camera_data(cam.position, cam.rotation, w, h)
+    want = oracle.to_rgba8(oracle.render(pos, rad, col, ocam, w, h), flip=True)
+    head = f"P6\n{w} {h}\n255\n".encode()
+    data = out.read_bytes()
+    img = np.frombuffer(data[len(head):], np.uint8).reshape(h, w, 3)
+    assert np.array_equal(img, want[..., :3])
+    assert int((img != 0).any(axis=-1).sum()) > 500      # the scripted camera still sees the scene
