@@ -55,7 +55,7 @@ def parse():
                     help="also time K frames end to end through the double-buffered read-back pipeline "
                          "(reported as end_to_end, never as value)")
     ap.add_argument("--no-cpu", action="store_true", help="skip the cpu_baseline leg")
-    ap.add_argument("--cpu-rows", type=int, default=0, help="rows of the frame the CPU baseline renders (0 = auto)")
+    ap.add_argument("--cpu-threads", type=int, default=0, help="threads of the cpu_baseline leg (0 = OMP_NUM_THREADS, else min(cores, 16))")
     return ap.parse_args()
 
 
@@ -419,7 +419,7 @@ def main():
         if end_to_end is not None:
             out["end_to_end"] = end_to_end
         if not args.no_cpu and world == 1:
-            threads = int(os.environ.get("OMP_NUM_THREADS", "0")) or min(os.cpu_count() or 1, 16)
+            threads = args.cpu_threads or int(os.environ.get("OMP_NUM_THREADS", "0")) or min(os.cpu_count() or 1, 16)
             out["cpu_baseline"] = cpu_baseline(cfg, threads, args.shading)
             out["gpu_over_cpu"] = value / out["cpu_baseline"]["value"]
         else:
