@@ -155,6 +155,12 @@ def main():
     if args.gpus > 1 and world == 1:
         raise SystemExit("for --gpus N>1 launch with: python -m torch.distributed.run --nproc-per-node N bench.py --gpus N ...")
 
+    # stdout carries exactly one line, the JSON result: anything libraries print there (RCCL
+    # writes a version banner to stdout when it initialises) is sent to stderr instead
+    sys.stdout.flush()
+    result_fd = os.dup(1)
+    os.dup2(2, 1)
+
     import torch
     import torch.distributed as dist
     if not torch.cuda.is_available():
@@ -267,6 +273,8 @@ def main():
     abi.check(lib.rc_event_elapsed_ms(ev0, ev1, C.byref(ev_ms)))
 
     dt_max = sharding.max_over_ranks(dt, comm_device)
+    # per-GPU time of the K steps on each rank's own stream (load balance of bands / frames)
+    per_rank_ms = sharding.gather_floats(ev_ms.value / args.steps, comm_device) if use_dist else None
 
     # Per-frame distribution (median, p10, p90): 100 more frames, each between
     # its own pair of HIP events, outside the timed region.
@@ -392,7 +400,7 @@ def main():
                        "variant": args.variant, "sharding": args.mode, "backend": backend if world > 1 else None,
                        "camera": "sequence" if args.sequence else "static",
                        "device": name.value.decode(), "compute_units": cu.value, "clock_mhz": khz.value / 1e3},
-            "frame_ms": kernel_ms, "frame_ms_stats": frame_stats,
+            "frame_ms": kernel_ms, "frame_ms_stats": frame_stats, "per_rank_step_ms": per_rank_ms,
             "roofline": {
                 # "mfma" = the compute roofline of the contract's two (hbm | mfma); the kernel issues NO MFMA:
                 # it is bound by the FP32 vector ALU, whose peak equals the dense f32 MFMA peak (157.3 TFLOP/s)
@@ -424,7 +432,8 @@ def main():
             out["gpu_over_cpu"] = value / out["cpu_baseline"]["value"]
         else:
             out["cpu_baseline"] = None
-        print(json.dumps(out), flush=True)
+        sys.stdout.flush()
+        os.write(result_fd, (json.dumps(out) + "\n").encode())
 
     if use_dist:
         dist.destroy_process_group()

@@ -120,3 +120,13 @@ def max_over_ranks(value, device):
     if dist.is_available() and dist.is_initialized():
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
     return float(t.item())
+
+
+def gather_floats(value, device):
+    """One python float per rank -> list over ranks, on every rank (per-GPU kernel times)."""
+    if not (dist.is_available() and dist.is_initialized()):
+        return [float(value)]
+    mine = torch.tensor([value], dtype=torch.float64, device=device)
+    parts = [torch.zeros_like(mine) for _ in range(dist.get_world_size())]
+    dist.all_gather(parts, mine)
+    return [float(p.item()) for p in parts]

@@ -36,6 +36,7 @@ def _worker(rank, world, port, w, h, n, out_path):
         sharding.gather_bands(torch.from_numpy(band), full, h, world, rank, dst=0)
         t = sharding.max_over_ranks(float(rank + 1), "cpu")
         assert t == float(world)
+        assert sharding.gather_floats(0.5 * rank, "cpu") == [0.5 * r for r in range(world)]
         dist.barrier()
         if rank == 0:
             np.save(out_path, full.numpy())
