@@ -55,6 +55,8 @@ def parse():
                     help="also time K frames end to end through the double-buffered read-back pipeline "
                          "(reported as end_to_end, never as value)")
     ap.add_argument("--no-cpu", action="store_true", help="skip the cpu_baseline leg")
+    ap.add_argument("--no-clock-ramp", action="store_true",
+                    help="do not extend the untimed warm-up until the GPU has reached its steady clock")
     ap.add_argument("--cpu-threads", type=int, default=0, help="threads of the cpu_baseline leg (0 = OMP_NUM_THREADS, else min(cores, 16))")
     return ap.parse_args()
 
@@ -259,13 +261,29 @@ def main():
     for i in range(args.warmup):
         step(i)
     fence()
+    # Clock ramp: an idle MI355X needs ~30 ms of continuous work to reach its steady clock
+    # (tools/ramp_probe.py: the first 80 frames of this workload run up to 35 % slower), so the
+    # untimed warm-up is extended until the GPU has been busy for ~0.1 s.  The count is agreed
+    # over ranks (bands mode needs every rank to run the same number of steps).
+    ramp_steps = 0
+    if not args.no_clock_ramp:
+        t_p = time.perf_counter()
+        for i in range(8):
+            step(args.warmup + i)
+        torch.cuda.current_stream().synchronize()
+        est = max((time.perf_counter() - t_p) / 8, 1e-6)
+        ramp_steps = 8 + int(sharding.max_over_ranks(float(min(4096, int(0.1 / est) + 1)), comm_device))
+        for i in range(8, ramp_steps):
+            step(args.warmup + i)
+        fence()
+    first = args.warmup + ramp_steps
     ev0, ev1 = C.c_void_p(), C.c_void_p()
     abi.check(lib.rc_event_create(C.byref(ev0)))
     abi.check(lib.rc_event_create(C.byref(ev1)))
     t0 = time.perf_counter()
     abi.check(lib.rc_event_record(ev0, stream))
     for i in range(args.steps):
-        step(args.warmup + i)
+        step(first + i)
     abi.check(lib.rc_event_record(ev1, stream))
     fence()
     dt = time.perf_counter() - t0
@@ -287,7 +305,7 @@ def main():
             evs.append(e)
         abi.check(lib.rc_event_record(evs[0], stream))
         for i in range(100):
-            step(args.warmup + args.steps + i)
+            step(first + args.steps + i)
             abi.check(lib.rc_event_record(evs[i + 1], stream))
         torch.cuda.synchronize()
         per = []
@@ -392,6 +410,7 @@ def main():
         out = {
             "metric": "primary Mrays/sec at %dx%d, %d spheres" % (w, h, n),
             "value": value, "unit": "Mrays/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "warmup_clock_ramp_steps": ramp_steps,
             "ms_per_step": dt_max / args.steps * 1e3, "higher_is_better": True,
             "scaling": "weak" if args.mode == "frames" else "strong",
             "vs_baseline": None, "dtype": "f32", "data": "synthetic",
