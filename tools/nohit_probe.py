@@ -24,7 +24,7 @@ for scale in (1.0, 1e-4):
         opts = abi.RcOpts(variant=variant)
         e0, e1 = C.c_void_p(), C.c_void_p()
         lib.rc_event_create(C.byref(e0)); lib.rc_event_create(C.byref(e1))
-        for _ in range(20): lib.rc_render(C.byref(screen), C.byref(scene), C.byref(opts))
+        for _ in range(400): lib.rc_render(C.byref(screen), C.byref(scene), C.byref(opts))   # through the clock ramp
         lib.rc_sync(None)
         lib.rc_event_record(e0, None)
         for _ in range(200): lib.rc_render(C.byref(screen), C.byref(scene), C.byref(opts))
