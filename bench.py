@@ -338,7 +338,7 @@ def main():
         cms = C.c_float()
         abi.check(lib.rc_event_elapsed_ms(ev0, ev1, C.byref(cms)))
         cms = cms.value / args.steps
-        culled = {"variant": "culled (RC_VARIANT_CULLED, opt-in): per-wave-tile interval test in front of the per-pixel loop; "
+        culled = {"variant": "culled (RC_VARIANT_CULLED, opt-in): interval tests per workgroup tile, then per wave tile, in place of the per-pixel loop; "
                              "bit-identical surfaces, not one test per (pixel, sphere) pair",
                   "value": w * h / (cms * 1e-3) / 1e6, "unit": "Mrays/s", "frame_ms": cms,
                   "roofline": {"bound": "hbm", "achieved": 16.0 * w * h / (cms * 1e-3) / 1e9, "peak": HBM_PEAK_GBS,

@@ -4,6 +4,7 @@
 #include <stddef.h>
 #include <stdint.h>
 
+#define RC_CULL_CHUNK_MAX 1024  // culled variant: spheres per pass (see rc_launch_tiled)
 #define RC_LDS_CHUNK_MAX 4096   // most spheres staged in LDS per pass (13 bytes each: 52 KiB)
 
 enum { RC_KVARIANT_AUTO = 0, RC_KVARIANT_LITERAL = 1, RC_KVARIANT_TILED4 = 2, RC_KVARIANT_TILED2 = 3, RC_KVARIANT_TILED8 = 4 };

@@ -71,8 +71,8 @@ enum {
     RC_VARIANT_TILED_P2 = 3, /* tuning: the tiled kernel forced to 2 pixels per lane       */
     RC_VARIANT_TILED_P8 = 4, /* tuning: forced to 8 pixels per lane (REF mode; EXT uses 4)  */
     RC_VARIANT_TILED_P4 = 5, /* tuning: forced to 4 pixels per lane                         */
-    RC_VARIANT_CULLED = 6    /* opt-in: the tiled kernel with a per-wave-tile interval test in
-                                front of the per-pixel loop; spheres that cannot touch a tile
+    RC_VARIANT_CULLED = 6    /* opt-in: interval tests per workgroup tile, then per wave tile, in
+                                place of the per-pixel loop; spheres that cannot touch a tile
                                 are never tested against its pixels.  Same surfaces, but no
                                 longer one test per (pixel, sphere) pair.                     */
 };
