@@ -140,3 +140,37 @@ def test_rgba8_rule(oracle):
     assert out[0, 2].tolist() == [64, 191, 0, 255]
     flipped = oracle.to_rgba8(surf, flip=True)
     assert np.array_equal(flipped[::-1], out)
+
+
+@pytest.mark.parametrize("cc,flags", [
+    ("gcc", ["-O0"]),
+    ("gcc", ["-O3", "-march=native"]),
+    ("/opt/rocm/lib/llvm/bin/clang", ["-O2"]),
+    ("/opt/rocm/lib/llvm/bin/clang", ["-O3", "-march=native"]),
+])
+def test_oracle_is_compiler_independent(oracle, ref_kat, kat_scene, tmp_path, cc, flags):
+    """With -ffp-contract=off the oracle's surface does not depend on compiler or optimisation
+    level (every operation is one IEEE binary32 rounding): each build reproduces the reference's
+    recorded hash at 64 spheres.  (-march=native enables FMA hardware; the flag must keep it unused.)"""
+    import ctypes as C
+    import shutil
+    if shutil.which(cc) is None and not os.path.exists(cc):
+        pytest.skip(f"{cc} not installed")
+    so = str(tmp_path / "liboracle_alt.so")
+    src = os.path.join(ROOT, "oracle", "rc_oracle.c")
+    subprocess.run([cc, *flags, "-ffp-contract=off", "-fno-fast-math", "-fPIC", "-shared", "-pthread", "-o", so, src, "-lm"],
+                   check=True, capture_output=True)
+    alt = C.CDLL(so)
+    alt.rco_render_rows.argtypes = [C.POINTER(oracle.Screen), C.POINTER(oracle.Scene), C.c_int, C.c_int, C.c_int, C.c_int, C.c_int]
+    alt.rco_render_rows.restype = None
+    alt.rco_fnv1a64_words.argtypes = [C.POINTER(oracle.Screen), C.c_uint64]
+    alt.rco_fnv1a64_words.restype = C.c_uint64
+    v = ref_kat["vectors"][1]
+    pos, rad, col = (a[: v["n"]] for a in kat_scene)
+    w, h = ref_kat["width"], ref_kat["height"]
+    cam = oracle.camera_data(ref_kat["camera_position"], ref_kat["camera_rotation"], w, h)
+    scene, keep = oracle.make_scene(pos, rad, col, cam)
+    surf = np.zeros((h, w, 4), np.float32)
+    scr = oracle.Screen(surf.ctypes.data, w, h, w * 16)
+    alt.rco_render_rows(C.byref(scr), C.byref(scene), 0, h, 0, h, 4)
+    assert f"{alt.rco_fnv1a64_words(C.byref(scr), ref_kat['fnv_offset_basis']):016x}" == v["fnv"]
