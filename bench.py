@@ -54,6 +54,8 @@ def parse():
     ap.add_argument("--readback", default="none", choices=["none", "rgba8", "float"],
                     help="also time K frames end to end through the double-buffered read-back pipeline "
                          "(reported as end_to_end, never as value)")
+    ap.add_argument("--graph", action="store_true",
+                    help="also capture the K steps into one HIP graph and time its replay (reported as graph_replay, never as value)")
     ap.add_argument("--no-cpu", action="store_true", help="skip the cpu_baseline leg")
     ap.add_argument("--no-clock-ramp", action="store_true",
                     help="do not extend the untimed warm-up until the GPU has reached its steady clock")
@@ -374,6 +376,47 @@ def main():
                            "Infinity Cache, so the achieved rate is a cache-assisted figure, not raw HBM",
                    "fused_frame_ms": fused_ms, "fused_extra_ms": fused_ms - ev_ms.value / args.steps}
 
+    # Secondary measurement (--graph, N=1): the same K steps captured into ONE HIP graph and replayed
+    # with a single submission -- what a launch-bound sequence of small frames gains.
+    graph_replay = None
+    if args.graph and world == 1 and args.mode == "frames":
+        gstream = C.c_void_p()
+        abi.check(lib.rc_stream_create(C.byref(gstream)))
+        gopts = abi.RcOpts.from_buffer_copy(bytes(opts))
+        gopts.ext = opts.ext
+        gopts.stream = gstream
+        abi.check(lib.rc_graph_begin(gstream), "rc_graph_begin")
+        for i in range(args.steps):
+            if args.sequence:
+                cam.position, cam.rotation = configs.sequence_camera(i % configs.SEQUENCE_FRAMES)
+                scene.cam = cam.get_data()
+            abi.check(lib.rc_render(C.byref(screen), C.byref(scene), C.byref(gopts)), "rc_render (capture)")
+        gexec = C.c_void_p()
+        abi.check(lib.rc_graph_end(gstream, C.byref(gexec)), "rc_graph_end")
+        g0, g1 = C.c_void_p(), C.c_void_p()
+        abi.check(lib.rc_event_create(C.byref(g0)))
+        abi.check(lib.rc_event_create(C.byref(g1)))
+        reps = 5
+        for i in range(2):
+            abi.check(lib.rc_graph_launch(gexec, gstream))
+        abi.check(lib.rc_sync(gstream))
+        t_g = time.perf_counter()
+        abi.check(lib.rc_event_record(g0, gstream))
+        for i in range(reps):
+            abi.check(lib.rc_graph_launch(gexec, gstream))
+        abi.check(lib.rc_event_record(g1, gstream))
+        abi.check(lib.rc_sync(gstream))
+        t_g = time.perf_counter() - t_g
+        gms = C.c_float()
+        abi.check(lib.rc_event_elapsed_ms(g0, g1, C.byref(gms)))
+        graph_replay = {"frames_per_graph": args.steps, "replays": reps,
+                        "frame_ms": gms.value / (reps * args.steps), "wall_ms_per_frame": t_g * 1e3 / (reps * args.steps),
+                        "value": w * h * reps * args.steps / t_g / 1e6, "unit": "Mrays/s"}
+        lib.rc_graph_destroy(gexec)
+        lib.rc_event_destroy(g0)
+        lib.rc_event_destroy(g1)
+        lib.rc_stream_destroy(gstream)
+
     end_to_end = None
     if args.readback != "none" and args.mode == "frames":
         end_to_end = pipelined_readback(lib, scene, opts, w, h, args.steps, args.warmup, args.readback)
@@ -443,6 +486,8 @@ def main():
             out["culled_variant"] = culled
         if display is not None:
             out["display_conversion"] = display
+        if graph_replay is not None:
+            out["graph_replay"] = graph_replay
         if end_to_end is not None:
             out["end_to_end"] = end_to_end
         if not args.no_cpu and world == 1:

@@ -90,6 +90,10 @@ SYMBOLS = {
     "rc_stream_wait_event": (C.c_int, [C.c_void_p, C.c_void_p]),
     "rc_host_alloc": (C.c_int, [C.POINTER(C.c_void_p), C.c_size_t]),
     "rc_host_free": (C.c_int, [C.c_void_p]),
+    "rc_graph_begin": (C.c_int, [C.c_void_p]),
+    "rc_graph_end": (C.c_int, [C.c_void_p, C.POINTER(C.c_void_p)]),
+    "rc_graph_launch": (C.c_int, [C.c_void_p, C.c_void_p]),
+    "rc_graph_destroy": (C.c_int, [C.c_void_p]),
     "rc_event_create": (C.c_int, [C.POINTER(C.c_void_p)]),
     "rc_event_record": (C.c_int, [C.c_void_p, C.c_void_p]),
     "rc_event_elapsed_ms": (C.c_int, [C.c_void_p, C.c_void_p, C.POINTER(C.c_float)]),

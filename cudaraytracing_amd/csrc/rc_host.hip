@@ -121,7 +121,7 @@ int rc_build_tables(int dev, uint32_t fb, float fov, int width, int full_height)
 // Looks the tables up, building them first if needed.  On success `lease` holds the shared
 // lock: the caller releases it after the kernel that reads the tables has been enqueued.
 int rc_get_tables(float fov, int width, int full_height, const float **sx, const float **sy,
-                  std::shared_lock<std::shared_mutex> &lease)
+                  std::shared_lock<std::shared_mutex> &lease, hipStream_t stream)
 {
     int dev = 0;
     RC_HIP(hipGetDevice(&dev));
@@ -131,6 +131,11 @@ int rc_get_tables(float fov, int width, int full_height, const float **sx, const
         lease = std::shared_lock<std::shared_mutex>(g_mu);
         if (rc_find_tables(dev, fb, width, full_height, sx, sy)) return RC_OK;
         lease.unlock();
+        if (stream) {       // building allocates and copies: not possible while the stream is being captured
+            hipStreamCaptureStatus st = hipStreamCaptureStatusNone;
+            if (hipStreamIsCapturing(stream, &st) == hipSuccess && st == hipStreamCaptureStatusActive)
+                return rc_fail_arg("frame format not prepared: call rc_prepare(width, full_height, fov) before capturing");
+        }
         std::unique_lock<std::shared_mutex> build(g_mu);
         int rc = rc_build_tables(dev, fb, fov, width, full_height);
         if (rc != RC_OK) return rc;
@@ -204,7 +209,7 @@ extern "C" int rc_render(const rc_screen *screen, const rc_scene *scene, const r
 
     const float *sx = nullptr, *sy = nullptr;
     std::shared_lock<std::shared_mutex> lease;     // held until the kernel is enqueued
-    int rc = rc_get_tables(scene->cam.fov, screen->width, full_height, &sx, &sy, lease);
+    int rc = rc_get_tables(scene->cam.fov, screen->width, full_height, &sx, &sy, lease, static_cast<hipStream_t>(o.stream));
     if (rc != RC_OK) return rc;
 
     RcKernArgs a;
@@ -271,7 +276,7 @@ extern "C" int rc_prepare(int width, int full_height, float fov)
     if (width > kMaxDim || full_height > kMaxDim) return rc_fail_arg("width/full_height above 65536");
     const float *sx = nullptr, *sy = nullptr;
     std::shared_lock<std::shared_mutex> lease;
-    return rc_get_tables(fov, width, full_height, &sx, &sy, lease);
+    return rc_get_tables(fov, width, full_height, &sx, &sy, lease, nullptr);
 }
 
 extern "C" int rc_to_rgba8(const rc_screen *screen, void *rgba8, size_t rgba8_pitch, int flip, void *stream)
@@ -449,6 +454,40 @@ extern "C" int rc_sync(void *stream)
 {
     if (stream) RC_HIP(hipStreamSynchronize(static_cast<hipStream_t>(stream)));
     else RC_HIP(hipDeviceSynchronize());
+    return RC_OK;
+}
+
+extern "C" int rc_graph_begin(void *stream)
+{
+    if (!stream) return rc_fail_arg("the default stream cannot be captured: pass a stream from rc_stream_create");
+    RC_HIP(hipStreamBeginCapture(static_cast<hipStream_t>(stream), hipStreamCaptureModeThreadLocal));
+    return RC_OK;
+}
+
+extern "C" int rc_graph_end(void *stream, void **graph_exec)
+{
+    if (!stream || !graph_exec) return rc_fail_arg("null stream or graph_exec");
+    hipGraph_t graph = nullptr;
+    RC_HIP(hipStreamEndCapture(static_cast<hipStream_t>(stream), &graph));
+    hipGraphExec_t exec = nullptr;
+    hipError_t e = hipGraphInstantiate(&exec, graph, nullptr, nullptr, 0);
+    (void)hipGraphDestroy(graph);
+    if (e != hipSuccess) return rc_fail_hip(e, "hipGraphInstantiate");
+    *graph_exec = exec;
+    return RC_OK;
+}
+
+extern "C" int rc_graph_launch(void *graph_exec, void *stream)
+{
+    if (!graph_exec) return rc_fail_arg("null graph_exec");
+    RC_HIP(hipGraphLaunch(static_cast<hipGraphExec_t>(graph_exec), static_cast<hipStream_t>(stream)));
+    return RC_OK;
+}
+
+extern "C" int rc_graph_destroy(void *graph_exec)
+{
+    if (!graph_exec) return RC_OK;
+    RC_HIP(hipGraphExecDestroy(static_cast<hipGraphExec_t>(graph_exec)));
     return RC_OK;
 }
 

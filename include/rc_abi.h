@@ -177,6 +177,19 @@ int rc_host_free(void *ptr);
 int rc_download_2d_async(void *dst_host, size_t dst_pitch, const void *src_device, size_t src_pitch,
                          size_t width_bytes, size_t height, void *stream);
 
+/* HIP graphs for launch-bound sequences (small frames: a 640x480 x 8-sphere frame renders in less
+ * time than one launch costs).  Everything enqueued on `stream` between rc_graph_begin and
+ * rc_graph_end -- rc_render with any scene and camera (the arguments are baked into each node),
+ * rc_to_rgba8, rc_download_2d_async -- is recorded instead of executed; rc_graph_launch replays the
+ * whole sequence with one submission.  `stream` must be a stream from rc_stream_create (the default
+ * stream cannot be captured), and rc_prepare (or one earlier rc_render) must have built the sine
+ * tables of every frame format used inside the capture, because a capture cannot allocate.  No
+ * counterpart in the reference, which launches frame by frame (RayTracingKernel.cpp:17). */
+int rc_graph_begin(void *stream);
+int rc_graph_end(void *stream, void **graph_exec);
+int rc_graph_launch(void *graph_exec, void *stream);
+int rc_graph_destroy(void *graph_exec);
+
 /* HIP events on the stream the kernels run on (the reference only has a wall clock,
  * main.cpp:45-50) */
 int rc_event_create(void **event);

@@ -557,3 +557,47 @@ def test_cli_input_script_replay(oracle, tmp_path):
     img = np.frombuffer(data[len(head):], np.uint8).reshape(h, w, 3)
     assert np.array_equal(img, want[..., :3])
     assert int((img != 0).any(axis=-1).sum()) > 500      # the scripted camera still sees the scene
+
+
+def test_graph_capture_and_replay(oracle, rclib):
+    """A 10-frame camera sequence captured into one HIP graph (rc_graph_begin/end) and replayed
+    twice: every frame of every replay equals the oracle's frame for that camera; a frame format
+    that was not prepared is refused inside a capture instead of allocating."""
+    from cudaraytracing_amd.host import DeviceBuffer
+    w, h, n, frames = 200, 112, 40, 10
+    pos, rad, col = oracle.generate_scene(n, 5)
+    gs = GpuScene(pos, rad, col)
+    stream = C.c_void_p()
+    abi.check(rclib.rc_stream_create(C.byref(stream)))
+    cams = [oracle.camera_data(*configs.sequence_camera(7 * f), w, h) for f in range(frames)]
+    abi.check(rclib.rc_prepare(w, h, cams[0].fov))
+    surfs = [DeviceBuffer(w * 16 * h) for _ in range(frames)]
+    opts = abi.RcOpts(stream=stream)
+    abi.check(rclib.rc_graph_begin(stream), "rc_graph_begin")
+    for f in range(frames):
+        screen = abi.RcScreen(surfs[f].ptr.value, w, h, w * 16)
+        sc = gs.scene(cams[f])
+        abi.check(rclib.rc_render(C.byref(screen), C.byref(sc), C.byref(opts)), "rc_render in capture")
+    # an unprepared format inside the capture is rejected up front
+    odd = abi.RcScreen(surfs[0].ptr.value, w - 8, h - 8, w * 16)
+    sc = gs.scene(oracle.camera_data((0, 0, 20), (0, 0, 0), w - 8, h - 8))
+    assert rclib.rc_render(C.byref(odd), C.byref(sc), C.byref(opts)) == abi.RC_EINVAL
+    assert b"rc_prepare" in rclib.rc_last_error_string()
+    exe = C.c_void_p()
+    abi.check(rclib.rc_graph_end(stream, C.byref(exe)), "rc_graph_end")
+    want = [oracle.render(pos, rad, col, cams[f], w, h) for f in range(frames)]
+    for replay in range(2):
+        for s in surfs:
+            abi.check(rclib.rc_memset(s.ptr, 0x55, w * 16 * h, stream))
+        abi.check(rclib.rc_graph_launch(exe, stream), "rc_graph_launch")
+        abi.check(rclib.rc_sync(stream))
+        for f in range(frames):
+            got = np.empty((h, w, 4), np.float32)
+            abi.check(rclib.rc_download_2d(got.ctypes.data_as(C.c_void_p), w * 16, surfs[f].ptr, w * 16, w * 16, h, stream))
+            assert_same_bits(got, want[f], f"replay {replay} frame {f}")
+    abi.check(rclib.rc_graph_destroy(exe))
+    assert rclib.rc_graph_begin(None) == abi.RC_EINVAL
+    for s in surfs:
+        s.free()
+    gs.free()
+    abi.check(rclib.rc_stream_destroy(stream))
