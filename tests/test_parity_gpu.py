@@ -268,8 +268,42 @@ def test_ext_ragged_and_multichunk(oracle):
         cam = oracle.camera_data((0.5, -0.25, 21.0), (0.05, 0.1, 0.0), w, h)
         ext = _default_ext(oracle)
         want = oracle.render(pos, rad, col, cam, w, h, ext=ext)
-        got = pixels(gpu_render(pos, rad, col, cam, w, h, ext=ext), w)
-        assert_same_bits(got, want, f"EXT {w}x{h} n={n}")
+        for variant in (abi.VARIANT_AUTO, abi.VARIANT_CULLED):
+            got = pixels(gpu_render(pos, rad, col, cam, w, h, variant=variant, ext=ext), w)
+            assert_same_bits(got, want, f"EXT {w}x{h} n={n} variant {variant}")
+
+
+def test_ext_soak_tiled_vs_literal_on_device(oracle):
+    """EXT mode, filter soundness incl. the shadow-ray filter: random scenes, lights and planes with
+    the camera and the light near sphere surfaces; tiled / culled kernels against the literal EXT
+    kernel on the device (RC_EXT_SOAK_SCENES scenes, RC_SOAK_SEED)."""
+    rng = np.random.default_rng(int(os.environ.get("RC_SOAK_SEED", "99")) + 1)
+    w, h = 160, 88
+    variants = [abi.VARIANT_TILED2, abi.VARIANT_TILED4, abi.VARIANT_CULLED]
+    for it in range(int(os.environ.get("RC_EXT_SOAK_SCENES", "150"))):
+        n = int(rng.integers(1, 90))
+        spread = 10.0 ** rng.uniform(-0.5, 1.5)
+        pos = rng.uniform(-spread, spread, (n, 3)).astype(np.float32)
+        rad = (spread * 10.0 ** rng.uniform(-2.5, -0.3, n)).astype(np.float32)
+        col = rng.uniform(0, 1, (n, 3)).astype(np.float32)
+        k, kl = int(rng.integers(n)), int(rng.integers(n))
+        dirv = rng.normal(size=3); dirv /= np.linalg.norm(dirv)
+        dirl = rng.normal(size=3); dirl /= np.linalg.norm(dirl)
+        cpos = tuple(float(v) for v in (pos[k] + dirv * rad[k] * (1.0 + 10.0 ** rng.uniform(-6, 1))))
+        # the light from 1e-6 radii off a sphere's surface (or inside it) to far away
+        lpos = tuple(float(v) for v in (pos[kl] + dirl * rad[kl] * (1.0 + rng.choice([-1.0, 1.0]) * 10.0 ** rng.uniform(-6, 1.5))))
+        f = -dirv
+        rot = (float(np.arcsin(np.clip(f[1], -1, 1))) + float(rng.normal() * 0.2), float(np.arctan2(-f[0], -f[2])) + float(rng.normal() * 0.2), 0.0)
+        cam = oracle.camera_data(cpos, rot, w, h)
+        ext = _default_ext(oracle, light_pos=lpos, plane_normal=tuple(float(v) for v in rng.normal(size=3)),
+                           plane_h=float(rng.uniform(-spread, spread)), has_plane=int(rng.integers(2)))
+        scene = GpuScene(pos, rad, col)
+        want = pixels(gpu_render(pos, rad, col, cam, w, h, variant=abi.VARIANT_LITERAL, scene=scene, ext=ext), w)
+        got = pixels(gpu_render(pos, rad, col, cam, w, h, variant=variants[it % 3], scene=scene, ext=ext), w)
+        scene.free()
+        assert_same_bits(got, want, f"EXT soak {it}: n={n} cam={cpos} light={lpos} variant={variants[it % 3]}")
+        if it % 5000 == 4999:
+            print(f"EXT soak: {it + 1} scenes identical", flush=True)
 
 
 def test_ext_requires_parameters(rclib):
