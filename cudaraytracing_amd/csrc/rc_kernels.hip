@@ -406,6 +406,13 @@ __device__ __forceinline__ float rc_wave_max(float v)
     return v;
 }
 
+__device__ __forceinline__ float rc_wave_sum(float v)
+{
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v = v + __shfl_xor(v, o, 64);
+    return v;
+}
+
 // Shadow-ray filter record of one sphere for rays that all start at the light:
 // h = -(light - pos) * k with the same k as above (c taken from the light).  A shadow ray
 // with unit direction e can meet the sphere in front of the light only if h.e >= 1 up to
@@ -435,7 +442,17 @@ __device__ __forceinline__ RcLightRecord rc_prepass_light(const RcKernArgs &a, i
 // conservative FMA filter, exact re-test of what the filter cannot rule out); the rays share
 // the light as origin but their directions are arbitrary, so the filter is the 3-FMA dot
 // product h.e >= 1 instead of the separable form.
-template <int P>
+//
+// Culled variant (CULL): instead of testing every hit pixel against every sphere, each wave bounds
+// its shadow rays by a cone (axis c = the normalised sum of the tile's ray directions, half-angle
+// phi = the largest angle between a ray and c) and lane l tests sphere 64 it + l against the cone:
+// for a unit e within phi of c, h.e <= |h| if h itself lies within phi of c, and otherwise
+// h.e <= (h.c) cos phi + |h - (h.c) c| sin phi.  Spheres whose bound stays below 1 are flagged by no
+// pixel of the tile; the others are visited one by one with the per-pixel filter and the exact
+// test.  The cone is widened (cos phi lowered by 2^-18, the perpendicular part of h raised by
+// 2^-10 |h|, the bound by 2^-16) well beyond the float errors of its own evaluation, and tiles
+// whose rays do not fit a cone narrower than 90 degrees test every sphere.
+template <int P, bool CULL>
 __device__ __forceinline__ void rc_shadow_pass(const RcKernArgs &a, char *lds,
                                                const float (&ex)[P], const float (&ey)[P], const float (&ez)[P],
                                                const float (&limit)[P], const int (&idx)[P], bool (&shadowed)[P])
@@ -459,6 +476,28 @@ __device__ __forceinline__ void rc_shadow_pass(const RcKernArgs &a, char *lds,
     for (int p = 0; p < P; p++) any_hit = any_hit || (idx[p] != -1);
     const bool wave_has_hits = __builtin_amdgcn_ballot_w64(any_hit) != 0ull;   // no hit pixel: no shadow rays
 
+    float cax = 0.0f, cay = 0.0f, caz = 0.0f, ccos = 1.0f, csin = 0.0f;
+    bool cone_forced = (forced_mask != 0ull);
+    if (CULL && wave_has_hits) {
+        float sx = 0.0f, sy = 0.0f, sz = 0.0f;                 // misses carry e = 0
+#pragma unroll
+        for (int p = 0; p < P; p++) { sx += ex[p]; sy += ey[p]; sz += ez[p]; }
+        sx = rc_wave_sum(sx); sy = rc_wave_sum(sy); sz = rc_wave_sum(sz);
+        const float ss = __builtin_fmaf(sz, sz, __builtin_fmaf(sy, sy, sx * sx));
+        const float inv = __builtin_amdgcn_rsqf(ss);
+        cax = sx * inv; cay = sy * inv; caz = sz * inv;
+        float cmin = 2.0f;
+#pragma unroll
+        for (int p = 0; p < P; p++) {
+            const float ce = __builtin_fmaf(ez[p], caz, __builtin_fmaf(ey[p], cay, ex[p] * cax));
+            if (idx[p] != -1) cmin = fminf(cmin, ce);
+        }
+        cmin = rc_wave_min(cmin);
+        ccos = cmin - 0x1p-18f;
+        if (!(ss > 0x1p-20f) || !(ss < 0x1p40f) || !(ccos > 0.0f) || !(ccos <= 1.0f)) cone_forced = true;
+        csin = __builtin_amdgcn_sqrtf(fmaxf(__builtin_fmaf(-ccos, ccos, 1.0f), 0.0f)) * (1.0f + 0x1p-18f) + 0x1p-20f;
+    }
+
     for (int base = 0; base < a.n; base += cap) {
         const int cn = min(a.n - base, cap);
         const int cnb = (cn + kBlockSpheres - 1) & ~(kBlockSpheres - 1);
@@ -480,7 +519,54 @@ __device__ __forceinline__ void rc_shadow_pass(const RcKernArgs &a, char *lds,
         }
         __syncthreads();
         const unsigned long long flag0_mask = (*s_has_always != 0) ? ~0ull : forced_mask;
-        const int nblocks = wave_has_hits ? cnb / kBlockSpheres : 0;
+        const int nblocks = (wave_has_hits && !CULL) ? cnb / kBlockSpheres : 0;
+
+        if (CULL && wave_has_hits) {
+            const float *rec = reinterpret_cast<const float *>(s_rec);
+            const unsigned char *flagb = reinterpret_cast<const unsigned char *>(s_flag);
+            const int lane = tid & 63;
+            const int iters = (cn + 63) >> 6;
+            for (int it = 0; it < iters; it++) {
+                const int jl = (it << 6) + lane;
+                unsigned long long cand_mask;
+                {
+                    const int jc = min(jl, cnb - 1);
+                    const float *g = rec + (jc >> 2) * 12 + (jc & 3);
+                    const float hx = g[0], hy = g[4], hz = g[8];
+                    const float hp = __builtin_fmaf(hz, caz, __builtin_fmaf(hy, cay, hx * cax));
+                    const float hh = __builtin_fmaf(hz, hz, __builtin_fmaf(hy, hy, hx * hx));
+                    const float hl = __builtin_amdgcn_sqrtf(hh) * (1.0f + 0x1p-20f);
+                    const float hperp = __builtin_amdgcn_sqrtf(fmaxf(__builtin_fmaf(-hp, hp, hh), 0.0f)) + 0x1p-10f * hl;
+                    const bool inside = hp * (1.0f + 0x1p-18f) >= hl * ccos;
+                    const float bound = inside ? hl : __builtin_fmaf(hperp, csin, hp * ccos);
+                    const bool c = (jl < cn) && (cone_forced || flagb[jc] != 0 || !(bound * (1.0f + 0x1p-16f) < 1.0f));
+                    cand_mask = __builtin_amdgcn_ballot_w64(c);
+                }
+                while (cand_mask != 0ull) {
+                    const int bit = __builtin_ctzll(cand_mask);
+                    cand_mask &= cand_mask - 1ull;
+                    const int j = (it << 6) + bit;
+                    const float *g = rec + (j >> 2) * 12 + (j & 3);
+                    const float hx = g[0], hy = g[4], hz = g[8];
+                    const bool all = lane_forced || (flagb[j] != 0);
+                    unsigned long long pm[P], any = 0ull;
+#pragma unroll
+                    for (int p = 0; p < P; p++) {
+                        const float t = __builtin_fmaf(ez[p], hz, __builtin_fmaf(ey[p], hy, ex[p] * hx));
+                        pm[p] = __builtin_amdgcn_ballot_w64(all || (t >= 1.0f));
+                        any |= pm[p];
+                    }
+                    if (any == 0ull) continue;
+                    const RcExactSphere e = rc_exact_sphere_from(a, base + j, a.lgx, a.lgy, a.lgz);
+#pragma unroll
+                    for (int p = 0; p < P; p++) {
+                        if (pm[p] == 0ull) continue;
+                        const float dist = rc_exact_dist(e, ex[p], ey[p], ez[p]);
+                        if (base + j != idx[p] && dist > 0.0f && dist < limit[p]) shadowed[p] = true;
+                    }
+                }
+            }
+        }
 
         for (int blk = 0; blk < nblocks; blk++) {
             float m[P];
@@ -789,7 +875,7 @@ __device__ __forceinline__ void rc_tiled_body(const RcKernArgs &a, char *lds)
                     ex[p] = 0.0f; ey[p] = 0.0f; ez[p] = 0.0f; limit[p] = -1.0f;   // misses cast no shadow ray
                     if (idx[p] != -1) rc_ext_ray(a, minDist[p], dx[p], dy[p], dz[p], ex[p], ey[p], ez[p], limit[p]);
                 }
-                rc_shadow_pass<P>(a, lds, ex, ey, ez, limit, idx, shadowed);
+                rc_shadow_pass<P, CULL>(a, lds, ex, ey, ez, limit, idx, shadowed);
 #pragma unroll
                 for (int p = 0; p < P; p++)
                     if (idx[p] != -1 && rc_plane_shadow(a, idx[p], ex[p], ey[p], ez[p], limit[p])) shadowed[p] = true;
