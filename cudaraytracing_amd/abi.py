@@ -100,6 +100,19 @@ SYMBOLS = {
     "rc_event_destroy": (C.c_int, [C.c_void_p]),
     "rc_camera_data": (None, [C.POINTER(RcVec3), C.POINTER(RcVec3), C.c_int, C.c_int, C.POINTER(RcCamera)]),
     "rc_handle_input": (C.c_int, [C.POINTER(RcVec3), C.POINTER(RcVec3), C.c_float, C.c_float, C.c_float, C.POINTER(RcInput)]),
+    "rc_ctx_create": (C.c_int, [C.POINTER(C.c_void_p), C.c_int, C.c_int, C.c_int]),
+    "rc_ctx_destroy": (C.c_int, [C.c_void_p]),
+    "rc_scene_generate": (C.c_int, [C.c_void_p, C.c_int, C.c_uint32]),
+    "rc_scene_upload": (C.c_int, [C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p]),
+    "rc_camera_set": (C.c_int, [C.c_void_p, C.POINTER(RcVec3), C.POINTER(RcVec3)]),
+    "rc_camera_input": (C.c_int, [C.c_void_p, C.POINTER(RcInput), C.c_float]),
+    "rc_surface_alloc": (C.c_int, [C.c_void_p, C.POINTER(C.c_size_t)]),
+    "rc_ctx_render": (C.c_int, [C.c_void_p, C.POINTER(RcOpts)]),
+    "rc_readback": (C.c_int, [C.c_void_p, C.c_void_p, C.c_size_t]),
+    "rc_readback_rgba8": (C.c_int, [C.c_void_p, C.c_void_p, C.c_size_t, C.c_int]),
+    "rc_ctx_write_ppm": (C.c_int, [C.c_void_p, C.c_char_p]),
+    "rc_ctx_screen": (C.POINTER(RcScreen), [C.c_void_p]),
+    "rc_ctx_scene": (C.POINTER(RcScene), [C.c_void_p]),
     "rc_generate_scene": (None, [C.c_uint32, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p]),
     "rc_write_ppm": (C.c_int, [C.c_char_p, C.c_void_p, C.c_size_t, C.c_int, C.c_int]),
     "rc_last_error_string": (C.c_char_p, []),

@@ -10,9 +10,15 @@
 
 namespace rc {
 
+// A failed rc_* call as an exception that keeps the call's return code.
+struct Error : std::runtime_error {
+    int code;
+    Error(int c, const std::string &msg) : std::runtime_error(msg), code(c) {}
+};
+
 inline void check(int rc, const char *what)
 {
-    if (rc != RC_OK) throw std::runtime_error(std::string(what) + ": " + rc_last_error_string());
+    if (rc != RC_OK) throw Error(rc, std::string(what) + ": " + rc_last_error_string());
 }
 
 class SceneManager {

@@ -636,3 +636,154 @@ extern "C" int rc_write_ppm(const char *path, const uint8_t *rgba8, size_t pitch
 extern "C" const char *rc_last_error_string(void) { return g_err; }
 
 extern "C" const char *rc_version(void) { return "rc_hip 0.1 gfx950"; }
+
+// ---- context API: the C++ host classes (csrc/host/*.hpp) behind C entry points ----------------
+#include "host/rc_raycaster.hpp"
+
+struct rc_ctx {
+    int device = 0;
+    rc::RayTracingKernel rtk;
+};
+
+namespace {
+// runs `body` with the context's device current; C++ exceptions of the host classes become codes
+template <class F>
+int rc_ctx_call(rc_ctx *ctx, F body)
+{
+    if (!ctx) return rc_fail_arg("null context");
+    try {
+        RC_HIP(hipSetDevice(ctx->device));
+        body(ctx->rtk);
+        return RC_OK;
+    } catch (const rc::Error &e) {
+        return e.code;                 // g_err was set by the failing rc_* call
+    } catch (const std::exception &e) {
+        return rc_fail_arg(e.what());
+    }
+}
+} // namespace
+
+extern "C" int rc_ctx_create(rc_ctx **out, int device, int width, int height)
+{
+    if (!out) return rc_fail_arg("null ctx pointer");
+    if (width <= 0 || height <= 0 || width > kMaxDim || height > kMaxDim) return rc_fail_arg("width/height out of range");
+    int count = 0;
+    RC_HIP(hipGetDeviceCount(&count));
+    if (device < 0 || device >= count) return rc_fail_arg("no such device");
+    rc_ctx *ctx = new (std::nothrow) rc_ctx;
+    if (!ctx) return rc_fail_arg("out of host memory");
+    ctx->device = device;
+    ctx->rtk.screen.width = width;
+    ctx->rtk.screen.height = height;
+    ctx->rtk.sm.cam = rc::Camera(width, height);
+    ctx->rtk.sm.cam.position = rc_vec3{0.0f, 0.0f, 20.0f};       // SceneManager.cpp:5
+    ctx->rtk.sm.UpdateCamera();
+    *out = ctx;
+    return RC_OK;
+}
+
+extern "C" int rc_ctx_destroy(rc_ctx *ctx)
+{
+    if (!ctx) return RC_OK;
+    int rc = rc_ctx_call(ctx, [](rc::RayTracingKernel &k) { k.Cleanup(); });
+    delete ctx;
+    return rc;
+}
+
+extern "C" int rc_scene_generate(rc_ctx *ctx, int sphere_num, uint32_t seed)
+{
+    if (sphere_num < 0) return rc_fail_arg("sphere_num < 0");
+    return rc_ctx_call(ctx, [&](rc::RayTracingKernel &k) {
+        std::vector<rc_vec3> p((size_t)sphere_num), c((size_t)sphere_num);
+        std::vector<float> r((size_t)sphere_num);
+        rc_generate_scene(seed, sphere_num, p.data(), r.data(), c.data());
+        k.sm.SetScene(p, r, c);
+    });
+}
+
+extern "C" int rc_scene_upload(rc_ctx *ctx, int sphere_num, const rc_vec3 *position, const float *radius, const rc_vec3 *color)
+{
+    if (sphere_num < 0 || (sphere_num > 0 && (!position || !radius || !color))) return rc_fail_arg("rc_scene_upload arguments");
+    return rc_ctx_call(ctx, [&](rc::RayTracingKernel &k) {
+        k.sm.SetScene(std::vector<rc_vec3>(position, position + sphere_num), std::vector<float>(radius, radius + sphere_num),
+                      std::vector<rc_vec3>(color, color + sphere_num));
+    });
+}
+
+extern "C" int rc_camera_set(rc_ctx *ctx, const rc_vec3 *position, const rc_vec3 *rotation)
+{
+    if (!position || !rotation) return rc_fail_arg("null position or rotation");
+    return rc_ctx_call(ctx, [&](rc::RayTracingKernel &k) {
+        k.sm.cam.position = *position;
+        k.sm.cam.SetRotation(*rotation);
+        k.sm.UpdateCamera();
+    });
+}
+
+extern "C" int rc_camera_input(rc_ctx *ctx, const rc_input *input, float dt)
+{
+    if (!input) return rc_fail_arg("null input");
+    bool moved = false;
+    int rc = rc_ctx_call(ctx, [&](rc::RayTracingKernel &k) {
+        moved = k.sm.cam.HandleInput(*input, dt);
+        if (moved) k.sm.UpdateCamera();                             // main.cpp:126-127
+    });
+    return rc != RC_OK ? rc : (moved ? 1 : 0);
+}
+
+extern "C" int rc_surface_alloc(rc_ctx *ctx, size_t *pitch)
+{
+    return rc_ctx_call(ctx, [&](rc::RayTracingKernel &k) {
+        k.RegisterSurface();
+        if (pitch) *pitch = k.screen.pitch;
+    });
+}
+
+extern "C" int rc_ctx_render(rc_ctx *ctx, const rc_opts *opts)
+{
+    return rc_ctx_call(ctx, [&](rc::RayTracingKernel &k) {
+        if (!k.screen.surface) throw std::runtime_error("rc_ctx_render: no surface (call rc_surface_alloc)");
+        rc::check(rc_render(&k.screen, &k.sm.scene, opts), "rc_render");
+    });
+}
+
+extern "C" int rc_readback(rc_ctx *ctx, float *dst_host, size_t dst_pitch)
+{
+    if (!dst_host) return rc_fail_arg("null destination");
+    return rc_ctx_call(ctx, [&](rc::RayTracingKernel &k) {
+        if (!k.screen.surface) throw std::runtime_error("rc_readback: no surface");
+        rc::check(rc_sync(nullptr), "rc_sync");                      // RayTracingKernel.cpp:18
+        rc::check(rc_download_2d(dst_host, dst_pitch, k.screen.surface, k.screen.pitch, (size_t)k.screen.width * 16,
+                                 (size_t)k.screen.height, nullptr), "rc_download_2d");
+    });
+}
+
+extern "C" int rc_readback_rgba8(rc_ctx *ctx, uint8_t *dst_host, size_t dst_pitch, int flip)
+{
+    if (!dst_host) return rc_fail_arg("null destination");
+    return rc_ctx_call(ctx, [&](rc::RayTracingKernel &k) {
+        if (!k.screen.surface) throw std::runtime_error("rc_readback_rgba8: no surface");
+        const size_t pitch8 = (size_t)k.screen.width * 4;
+        if (dst_pitch < pitch8) throw std::runtime_error("rc_readback_rgba8: pitch < 4*width");
+        void *d8 = nullptr;
+        rc::check(rc_malloc(&d8, pitch8 * (size_t)k.screen.height), "rc_malloc(rgba8)");
+        int rc = rc_sync(nullptr);
+        if (rc == RC_OK) rc = rc_to_rgba8(&k.screen, d8, pitch8, flip, nullptr);
+        if (rc == RC_OK) rc = rc_download_2d(dst_host, dst_pitch, d8, pitch8, pitch8, (size_t)k.screen.height, nullptr);
+        rc_free(d8);
+        rc::check(rc, "rc_readback_rgba8");
+    });
+}
+
+extern "C" int rc_ctx_write_ppm(rc_ctx *ctx, const char *path)
+{
+    if (!path) return rc_fail_arg("null path");
+    return rc_ctx_call(ctx, [&](rc::RayTracingKernel &k) {
+        if (!k.screen.surface) throw std::runtime_error("rc_ctx_write_ppm: no surface");
+        rc::check(rc_sync(nullptr), "rc_sync");
+        k.WritePPM(path);
+    });
+}
+
+extern "C" const rc_screen *rc_ctx_screen(const rc_ctx *ctx) { return ctx ? &ctx->rtk.screen : nullptr; }
+extern "C" const rc_scene *rc_ctx_scene(const rc_ctx *ctx) { return ctx ? &ctx->rtk.sm.scene : nullptr; }

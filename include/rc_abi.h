@@ -227,6 +227,38 @@ void rc_generate_scene(uint32_t seed, int n, rc_vec3 *position, float *radius, r
 /* Binary PPM (P6) of a host RGBA8 image whose first row is the top of the picture. */
 int rc_write_ppm(const char *path, const uint8_t *rgba8, size_t pitch, int width, int height);
 
+/* ---- context: what the reference's RayTracingKernel + SceneManager objects do on the host ----
+ * One context owns a device, a camera, the device-resident sphere arrays and a pitched float-RGBA
+ * surface, as RayTracingKernel owns `screen` and `sm` (RayTracingKernel.h).  A convenience layer over
+ * the calls above for C and FFI callers; the C++ classes in csrc/host/ are the same layer in C++. */
+typedef struct rc_ctx rc_ctx;
+/* RayTracingKernel::Init (RayTracingKernel.cpp:34-45) without the scene: picks `device`, records the
+ * frame size, camera at (0,0,20) looking down -z (SceneManager.cpp:4-6). */
+int rc_ctx_create(rc_ctx **ctx, int device, int width, int height);
+/* RayTracingKernel::Cleanup + SceneManager::Cleanup (RayTracingKernel.cpp:97-102, SceneManager.cpp:48-53) */
+int rc_ctx_destroy(rc_ctx *ctx);
+/* SceneManager::InitScene's random spheres + upload (SceneManager.cpp:8-29), portable generator */
+int rc_scene_generate(rc_ctx *ctx, int sphere_num, uint32_t seed);
+/* the same upload (SceneManager.cpp:17-24) with the caller's HOST arrays */
+int rc_scene_upload(rc_ctx *ctx, int sphere_num, const rc_vec3 *position, const float *radius, const rc_vec3 *color);
+/* Camera position / rotation + SceneManager::UpdateCamera (SceneManager.cpp:55-57) */
+int rc_camera_set(rc_ctx *ctx, const rc_vec3 *position, const rc_vec3 *rotation);
+/* one HandleInput poll (main.cpp:53-128) on the context's camera; returns 1 if it moved */
+int rc_camera_input(rc_ctx *ctx, const rc_input *input, float dt);
+/* RegisterTexture's cudaMallocPitch + cudaMemset(1) (RayTracingKernel.cpp:93-94); pitch may be NULL */
+int rc_surface_alloc(rc_ctx *ctx, size_t *pitch);
+/* RayTracingKernel::Run's launch (RayTracingKernel.cpp:17); enqueue only, opts may be NULL */
+int rc_ctx_render(rc_ctx *ctx, const rc_opts *opts);
+/* replaces the interop copy of Run (RayTracingKernel.cpp:18-27): waits, then copies the float frame
+ * (row 0 = bottom) / its RGBA8 conversion (flip != 0: top row first) to HOST memory */
+int rc_readback(rc_ctx *ctx, float *dst_host, size_t dst_pitch);
+int rc_readback_rgba8(rc_ctx *ctx, uint8_t *dst_host, size_t dst_pitch, int flip);
+/* the frame as a binary PPM, top row first */
+int rc_ctx_write_ppm(rc_ctx *ctx, const char *path);
+/* the structs the context would pass to rc_render (device pointers inside; owned by the context) */
+const rc_screen *rc_ctx_screen(const rc_ctx *ctx);
+const rc_scene *rc_ctx_scene(const rc_ctx *ctx);
+
 const char *rc_last_error_string(void);
 /* "rc_hip <version> gfx950" */
 const char *rc_version(void);

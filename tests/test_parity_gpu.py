@@ -635,3 +635,58 @@ def test_graph_capture_and_replay(oracle, rclib):
         s.free()
     gs.free()
     abi.check(rclib.rc_stream_destroy(stream))
+
+
+def test_context_api_end_to_end(oracle, rclib, tmp_path):
+    """rc_ctx_*: the reference's RayTracingKernel + SceneManager life cycle through plain C calls --
+    create, random scene, surface, render, read back; then a caller scene, a camera move, one
+    scripted input poll, RGBA8 and PPM output.  Every frame equals the oracle's."""
+    w, h, n = 300, 170, 70
+    ctx = C.c_void_p()
+    abi.check(rclib.rc_ctx_create(C.byref(ctx), 0, w, h), "rc_ctx_create")
+    assert rclib.rc_ctx_render(ctx, None) == abi.RC_EINVAL            # no surface yet
+    assert b"rc_surface_alloc" in rclib.rc_last_error_string()
+    abi.check(rclib.rc_scene_generate(ctx, n, 3), "rc_scene_generate")
+    pitch = C.c_size_t()
+    abi.check(rclib.rc_surface_alloc(ctx, C.byref(pitch)), "rc_surface_alloc")
+    assert pitch.value >= w * 16 and pitch.value % 256 == 0
+    assert rclib.rc_ctx_screen(ctx).contents.width == w and rclib.rc_ctx_scene(ctx).contents.sphere_num == n
+    abi.check(rclib.rc_ctx_render(ctx, None), "rc_ctx_render")
+    got = np.empty((h, w, 4), np.float32)
+    abi.check(rclib.rc_readback(ctx, got.ctypes.data_as(C.c_void_p), w * 16), "rc_readback")
+    pos, rad, col = oracle.generate_scene(n, 3)
+    cam = oracle.camera_data((0, 0, 20), (0, 0, 0), w, h)              # the context's initial camera
+    assert_same_bits(got, oracle.render(pos, rad, col, cam, w, h), "context, generated scene")
+
+    # caller scene + camera move + one input poll
+    rng = np.random.default_rng(5)
+    pos2 = rng.uniform(-6, 6, (25, 3)).astype(np.float32); pos2[:, 2] -= 10
+    rad2 = rng.uniform(0.3, 1.5, 25).astype(np.float32)
+    col2 = rng.uniform(0, 1, (25, 3)).astype(np.float32)
+    abi.check(rclib.rc_scene_upload(ctx, 25, pos2.ctypes.data_as(C.c_void_p), rad2.ctypes.data_as(C.c_void_p),
+                                    col2.ctypes.data_as(C.c_void_p)), "rc_scene_upload")
+    p, r = abi.RcVec3(1.0, 0.5, 18.0), abi.RcVec3(0.05, -0.1, 0.0)
+    abi.check(rclib.rc_camera_set(ctx, C.byref(p), C.byref(r)), "rc_camera_set")
+    inp = abi.RcInput(rbutton=1, key_w=1, cursor_dx=2, cursor_dy=-1)
+    assert rclib.rc_camera_input(ctx, C.byref(inp), 0.0005) == 1
+    assert rclib.rc_camera_input(ctx, C.byref(abi.RcInput()), 0.0005) == 0
+    from cudaraytracing_amd.host import Camera
+    pc = Camera(w, h); pc.position, pc.rotation = (1.0, 0.5, 18.0), (np.float32(0.05).item(), np.float32(-0.1).item(), 0.0)
+    pc.handle_input(np.float32(0.0005).item(), "r w", (2, -1))
+    abi.check(rclib.rc_ctx_render(ctx, None), "rc_ctx_render")
+    abi.check(rclib.rc_readback(ctx, got.ctypes.data_as(C.c_void_p), w * 16), "rc_readback")
+    cam2 = oracle.camera_data(pc.position, pc.rotation, w, h)
+    want = oracle.render(pos2, rad2, col2, cam2, w, h)
+    assert_same_bits(got, want, "context, caller scene after input")
+    img = np.empty((h, w, 4), np.uint8)
+    abi.check(rclib.rc_readback_rgba8(ctx, img.ctypes.data_as(C.c_void_p), w * 4, 1), "rc_readback_rgba8")
+    want8 = oracle.to_rgba8(want, flip=True)
+    assert np.array_equal(img, want8)
+    ppm = tmp_path / "ctx.ppm"
+    abi.check(rclib.rc_ctx_write_ppm(ctx, str(ppm).encode()), "rc_ctx_write_ppm")
+    head = f"P6\n{w} {h}\n255\n".encode()
+    data = ppm.read_bytes()
+    assert data.startswith(head) and np.array_equal(np.frombuffer(data[len(head):], np.uint8).reshape(h, w, 3), want8[..., :3])
+    abi.check(rclib.rc_ctx_destroy(ctx), "rc_ctx_destroy")
+    assert rclib.rc_ctx_create(C.byref(ctx), 99, w, h) == abi.RC_EINVAL
+    assert rclib.rc_ctx_render(None, None) == abi.RC_EINVAL
