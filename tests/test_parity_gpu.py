@@ -162,7 +162,7 @@ def test_filter_soak_tiled_vs_literal_on_device(oracle):
     w, h = 192, 104
     variants = [abi.VARIANT_TILED2, abi.VARIANT_TILED4, abi.VARIANT_TILED8, abi.VARIANT_CULLED]
     for it in range(int(os.environ.get("RC_SOAK_SCENES", "600"))):
-        n = int(rng.integers(1, 120))
+        n = int(rng.integers(1, int(os.environ.get("RC_SOAK_NMAX", "120"))))
         spread = 10.0 ** rng.uniform(-1, 2)
         pos = rng.uniform(-spread, spread, (n, 3)).astype(np.float32)
         rad = (spread * 10.0 ** rng.uniform(-3, 0, n)).astype(np.float32)
