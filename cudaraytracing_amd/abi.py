@@ -51,7 +51,7 @@ class RcOpts(C.Structure):
     _fields_ = [("y_offset", C.c_int), ("full_height", C.c_int), ("variant", C.c_int),
                 ("mode", C.c_int), ("stream", C.c_void_p), ("rgba8", C.c_void_p),
                 ("rgba8_pitch", C.c_size_t), ("rgba8_flip", C.c_int), ("reserved1", C.c_int),
-                ("ext", C.POINTER(RcExt))]
+                ("ext", C.POINTER(RcExt)), ("workspace", C.c_void_p), ("workspace_bytes", C.c_size_t)]
 
 
 class RcInput(C.Structure):
@@ -71,6 +71,7 @@ assert C.sizeof(RcScene) == 88 and C.sizeof(RcScreen) == 24 and C.sizeof(RcExt) 
 # every symbol include/rc_abi.h declares: name -> (restype, argtypes)
 SYMBOLS = {
     "rc_render": (C.c_int, [C.POINTER(RcScreen), C.POINTER(RcScene), C.POINTER(RcOpts)]),
+    "rc_workspace_bytes": (C.c_size_t, [C.c_int]),
     "rc_prepare": (C.c_int, [C.c_int, C.c_int, C.c_float]),
     "rc_to_rgba8": (C.c_int, [C.POINTER(RcScreen), C.c_void_p, C.c_size_t, C.c_int, C.c_void_p]),
     "rc_device_count": (C.c_int, [C.POINTER(C.c_int)]),

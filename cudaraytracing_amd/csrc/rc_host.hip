@@ -265,9 +265,22 @@ extern "C" int rc_render(const rc_screen *screen, const rc_scene *scene, const r
     RC_HIP(hipGetDevice(&dev));
     rc = rc_compute_units(dev, &cus);
     if (rc != RC_OK) return rc;
+    if (a.cull && o.workspace && a.n > 0) {
+        if ((reinterpret_cast<uintptr_t>(o.workspace) & 15) != 0 || o.workspace_bytes < rc_workspace_bytes(a.n))
+            return rc_fail_arg("workspace must be 16-byte aligned and hold rc_workspace_bytes(sphere_num) bytes");
+        float4 *records = static_cast<float4 *>(o.workspace);
+        hipError_t er = rc_launch_records(a, records, static_cast<hipStream_t>(o.stream));
+        if (er != hipSuccess) return rc_fail_hip(er, "record kernel launch");
+        a.records = records;
+    }
     hipError_t e = rc_launch_draw(a, kv, cus, static_cast<hipStream_t>(o.stream));
     if (e != hipSuccess) return rc_fail_hip(e, "draw kernel launch");
     return RC_OK;
+}
+
+extern "C" size_t rc_workspace_bytes(int sphere_num)
+{
+    return sphere_num > 0 ? (size_t)sphere_num * 16 : 0;
 }
 
 extern "C" int rc_prepare(int width, int full_height, float fov)

@@ -42,11 +42,15 @@ struct RcKernArgs {
     float pcx, pcy, pcz;
     float lgx, lgy, lgz;     // point light position
     float specular;
+    // culled variant: sphere records built once per frame by rc_launch_records (else NULL)
+    const float4 *records;   // [n] {alpha, gamma, beta, always ? 1 : 0}
     // filled in by the tiled launcher
-    int lds_cap;             // spheres per LDS chunk (multiple of 16)
+    int lds_cap;             // spheres per LDS chunk (multiple of 32)
     int tiles_x, tiles_y;    // workgroup tiles covering the surface
 };
 
 hipError_t rc_launch_draw(const RcKernArgs &a, int variant, int compute_units, hipStream_t stream);
+// Builds the n filter records of the scene for this camera into `records` (16 bytes each).
+hipError_t rc_launch_records(const RcKernArgs &a, float4 *records, hipStream_t stream);
 hipError_t rc_launch_rgba8(const void *surface, size_t pitch, int width, int rows, void *out,
                            size_t out_pitch, int flip, hipStream_t stream);

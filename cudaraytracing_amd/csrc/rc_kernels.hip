@@ -744,7 +744,14 @@ __device__ __forceinline__ void rc_tiled_body(const RcKernArgs &a, char *lds)
                     if (jj < Q) {
                         RcRecord r;
                         r.alpha = kNever; r.gamma = 0.0f; r.beta = 0.0f; r.always = false;
-                        if (j < cn) r = rc_prepass_sphere(a, base + j);
+                        if (j < cn) {
+                            if (a.records) {           // built once per frame by rc_build_records
+                                const float4 v = a.records[base + j];
+                                r.alpha = v.x; r.gamma = v.y; r.beta = v.z; r.always = (v.w != 0.0f);
+                            } else {
+                                r = rc_prepass_sphere(a, base + j);
+                            }
+                        }
                         float *g = rec + (j >> 2) * 12 + (j & 3);
                         g[0] = r.alpha; g[4] = r.gamma; g[8] = r.beta;
                         flagb[j] = r.always ? 1 : 0;
@@ -909,6 +916,16 @@ __global__ __launch_bounds__(256, (EXT && P == 4) ? 4 : 1) void rc_draw_tiled(Rc
     rc_tiled_body<P, EXT, CULL>(a, rc_lds);
 }
 
+// Sphere records of one frame for the culled variant with a caller workspace: the same
+// rc_prepass_sphere every workgroup would otherwise repeat, once per sphere.
+__global__ __launch_bounds__(256) void rc_build_records(RcKernArgs a, float4 *out)
+{
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= a.n) return;
+    const RcRecord r = rc_prepass_sphere(a, i);
+    out[i] = make_float4(r.alpha, r.gamma, r.beta, r.always ? 1.0f : 0.0f);
+}
+
 // float RGBA -> RGBA8 (the display step that follows the path in the reference)
 __global__ __launch_bounds__(256) void rc_rgba8_kernel(const char *surface, size_t pitch, int width, int rows,
                                                        char *out, size_t out_pitch, int flip)
@@ -980,6 +997,13 @@ hipError_t rc_launch_draw(const RcKernArgs &a, int variant, int compute_units, h
     if (!a.ext_mode && !a.cull && rc_tile_count<8>(a) >= want) return rc_launch_tiled<8>(a, stream);
     if (rc_tile_count<4>(a) >= want) return rc_launch_tiled<4>(a, stream);
     return rc_launch_tiled<2>(a, stream);
+}
+
+hipError_t rc_launch_records(const RcKernArgs &a, float4 *records, hipStream_t stream)
+{
+    if (a.n <= 0) return hipSuccess;
+    hipLaunchKernelGGL(rc_build_records, dim3((a.n + 255) / 256), dim3(256), 0, stream, a, records);
+    return hipGetLastError();
 }
 
 hipError_t rc_launch_rgba8(const void *surface, size_t pitch, int width, int rows, void *out,

@@ -117,7 +117,16 @@ typedef struct rc_opts {
     int rgba8_flip;      /* != 0: surface row 0 goes to the LAST rgba8 row (top-down image)*/
     int reserved1;
     const rc_ext *ext;   /* HOST pointer, required when mode == RC_MODE_EXT                */
+    void *workspace;     /* optional DEVICE scratch, 16-byte aligned, rc_workspace_bytes(n) or more:
+                            RC_VARIANT_CULLED then builds the sphere records once per frame in it
+                            (a small kernel ahead of the draw kernel on the same stream) instead of
+                            once per workgroup.  Ignored by the other variants.  Frames in flight
+                            at the same time need a workspace each.                              */
+    size_t workspace_bytes;
 } rc_opts;
+
+/* bytes of rc_opts.workspace needed for a scene of sphere_num spheres (16 per sphere) */
+size_t rc_workspace_bytes(int sphere_num);
 
 /* ---- the hot path ---------------------------------------------------------------------- */
 

@@ -45,7 +45,7 @@ def to_rc_ext(ext):
 
 
 def gpu_render(pos, rad, col, cam, width, height, variant=abi.VARIANT_AUTO, y_offset=0, full_height=0,
-               pitch=None, want_rgba8=False, flip=False, fill=1, scene=None, ext=None):
+               pitch=None, want_rgba8=False, flip=False, fill=1, scene=None, ext=None, workspace=False):
     """Render through rc_render -> float32 [height, pitch/4] raw rows (and RGBA8 if asked)."""
     lib = abi.load()
     own = scene is None
@@ -64,6 +64,10 @@ def gpu_render(pos, rad, col, cam, width, height, variant=abi.VARIANT_AUTO, y_of
         rgba = DeviceBuffer(width * 4 * height)
         opts.rgba8, opts.rgba8_pitch, opts.rgba8_flip = rgba.ptr.value, width * 4, 1 if flip else 0
     sc = gs.scene(cam)
+    ws = None
+    if workspace:            # records built once per frame (culled variant)
+        ws = DeviceBuffer(max(lib.rc_workspace_bytes(gs.n), 16))
+        opts.workspace, opts.workspace_bytes = ws.ptr.value, ws.nbytes
     abi.check(lib.rc_render(C.byref(screen), C.byref(sc), C.byref(opts)), "rc_render")
     abi.check(lib.rc_sync(None), "rc_sync")
     raw = np.empty((height, pitch // 4), np.float32)
@@ -74,6 +78,8 @@ def gpu_render(pos, rad, col, cam, width, height, variant=abi.VARIANT_AUTO, y_of
         abi.check(lib.rc_download_2d(out8.ctypes.data_as(C.c_void_p), width * 4, rgba.ptr, width * 4, width * 4, height, None), "download8")
         rgba.free()
     surf.free()
+    if ws is not None:
+        ws.free()
     if own:
         gs.free()
     return (raw, out8) if want_rgba8 else raw
