@@ -67,6 +67,7 @@ MODE_EXT = 1
 
 assert C.sizeof(RcVec3) == 12 and C.sizeof(RcCamera) == 56
 assert C.sizeof(RcScene) == 88 and C.sizeof(RcScreen) == 24 and C.sizeof(RcExt) == 56
+assert C.sizeof(RcOpts) == 72 and RcOpts.workspace.offset == 56 and C.sizeof(RcInput) == 40
 
 # every symbol include/rc_abi.h declares: name -> (restype, argtypes)
 SYMBOLS = {

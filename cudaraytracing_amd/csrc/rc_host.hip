@@ -25,6 +25,9 @@ static_assert(sizeof(rc_camera) == 56, "Camera.h:8-19 layout");
 static_assert(sizeof(rc_scene) == 88, "Scene.h:4-13 layout");
 static_assert(sizeof(rc_screen) == 24, "Screen.h:3-9 layout");
 static_assert(sizeof(rc_ext) == 56, "rc_ext layout");
+static_assert(sizeof(rc_opts) == 72 && offsetof(rc_opts, stream) == 16 && offsetof(rc_opts, ext) == 48 &&
+              offsetof(rc_opts, workspace) == 56, "rc_opts layout (mirrored by the ctypes binding)");
+static_assert(sizeof(rc_input) == 40, "rc_input layout");
 static_assert(offsetof(rc_scene, position) == 8 && offsetof(rc_scene, radius) == 16 &&
               offsetof(rc_scene, color) == 24 && offsetof(rc_scene, cam) == 32, "Scene.h field offsets");
 static_assert(offsetof(rc_screen, width) == 8 && offsetof(rc_screen, height) == 12 &&
