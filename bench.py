@@ -48,6 +48,9 @@ def parse():
     ap.add_argument("--mode", default="frames", choices=["frames", "bands"])
     ap.add_argument("--sequence", action="store_true", help="animate the camera along the 300-frame path")
     ap.add_argument("--subbands", type=int, default=2, help="bands mode: pieces per band, rendered and sent one after the other")
+    ap.add_argument("--gather", default="float", choices=["float", "rgba8"],
+                    help="bands mode: what is gathered on rank 0 -- the float RGBA bands (16 B/pixel) or the fused "
+                         "RGBA8 bands (4 B/pixel, a quarter of the xGMI traffic)")
     ap.add_argument("--variant", default="tiled", choices=["tiled", "tiled2", "tiled4", "tiled8", "culled", "literal"])
     ap.add_argument("--shading", default="ref", choices=["ref", "ext"],
                     help="ref: the reference's math; ext: + plane, point light, Phong, hard shadows (unpinned by the reference)")
@@ -221,8 +224,15 @@ def main():
         opts.mode = abi.MODE_EXT
         opts.ext = C.pointer(rc_ext)
     full = None
-    if args.mode == "bands" and world > 1 and rank == 0:
-        full = torch.empty((h, w, 4), dtype=torch.float32, device="cuda")
+    banded = args.mode == "bands" and world > 1
+    gather8 = banded and args.gather == "rgba8"
+    frame8 = torch.empty((rows, w), dtype=torch.int32, device="cuda") if gather8 else None
+    if gather8:           # the draw kernel writes the display surface too; that one travels
+        opts.rgba8, opts.rgba8_pitch, opts.rgba8_flip = frame8.data_ptr(), w * 4, 0
+    if banded and rank == 0:
+        full = (torch.empty((h, w), dtype=torch.int32, device="cuda") if gather8
+                else torch.empty((h, w, 4), dtype=torch.float32, device="cuda"))
+    sent = frame8 if gather8 else frame          # what the band gather moves
 
     gatherer = sharding.BandGather(h, world, rank, parts=args.subbands) if (args.mode == "bands" and world > 1) else None
 
@@ -244,14 +254,16 @@ def main():
                     popts = abi.RcOpts.from_buffer_copy(bytes(opts))
                     popts.ext = opts.ext
                     popts.y_offset = sb
+                    if gather8:
+                        popts.rgba8 = frame8[sb - y0:].data_ptr()
                     abi.check(lib.rc_render(C.byref(piece), C.byref(scene), C.byref(popts)), "rc_render")
-                gatherer.piece_rendered(k, frame, full)
+                gatherer.piece_rendered(k, sent, full)
             gatherer.wait()
         else:                                   # rehearsal backend: stage through host memory
             abi.check(lib.rc_render(C.byref(screen), C.byref(scene), C.byref(opts)), "rc_render")
             torch.cuda.current_stream().synchronize()
-            host_full = torch.empty((h, w, 4), dtype=torch.float32) if rank == 0 else None
-            sharding.gather_bands(frame.cpu(), host_full, h, world, rank, dst=0)
+            host_full = torch.empty(full.shape, dtype=full.dtype) if rank == 0 else None
+            sharding.gather_bands(sent.cpu(), host_full, h, world, rank, dst=0)
             if rank == 0:
                 full.copy_(host_full)
 
@@ -321,6 +333,26 @@ def main():
         frame_stats = {"frames": 100, "median_ms": per[50], "p10_ms": per[10], "p90_ms": per[90], "min_ms": per[0], "max_ms": per[-1]}
     if use_dist:
         dist.barrier()
+
+    # Bands mode self-check (outside the timed region): one more gathered frame on rank 0 against the
+    # same frame rendered whole by rank 0 alone, bit for bit.
+    gather_check = None
+    if banded:
+        step(first + args.steps)
+        fence()
+        if rank == 0:
+            whole = torch.empty((h, w, 4), dtype=torch.float32, device="cuda")
+            wopts = abi.RcOpts.from_buffer_copy(bytes(opts))
+            wopts.ext = opts.ext
+            wopts.y_offset, wopts.full_height = 0, h
+            whole8 = torch.empty((h, w), dtype=torch.int32, device="cuda") if gather8 else None
+            if gather8:
+                wopts.rgba8 = whole8.data_ptr()
+            wscreen = abi.RcScreen(whole.data_ptr(), w, h, w * 16)
+            abi.check(lib.rc_render(C.byref(wscreen), C.byref(scene), C.byref(wopts)), "rc_render (check)")
+            torch.cuda.synchronize()
+            gather_check = bool(torch.equal(full, whole8 if gather8 else whole))
+        fence()
 
     # Secondary measurement (N=1, default variant only): the opt-in tile-culling variant on the same
     # workload.  It is NOT `value`: it no longer performs one test per (pixel, sphere) pair.
@@ -466,10 +498,10 @@ def main():
             "vs_baseline": None, "dtype": "f32", "data": "synthetic",
             "config": {"workload": args.config, "width": w, "height": h, "spheres": n,
                        "mode": "REF" if args.shading == "ref" else "EXT (plane + point light + Phong + hard shadows; unpinned by the reference)",
-                       "variant": args.variant, "sharding": args.mode, "backend": backend if world > 1 else None,
+                       "variant": args.variant, "sharding": args.mode, "gathered": (args.gather if banded else None), "backend": backend if world > 1 else None,
                        "camera": "sequence" if args.sequence else "static",
                        "device": name.value.decode(), "compute_units": cu.value, "clock_mhz": khz.value / 1e3},
-            "frame_ms": kernel_ms, "frame_ms_stats": frame_stats, "per_rank_step_ms": per_rank_ms,
+            "frame_ms": kernel_ms, "frame_ms_stats": frame_stats, "per_rank_step_ms": per_rank_ms, "gather_check": gather_check,
             "roofline": {
                 # "mfma" = the compute roofline of the contract's two (hbm | mfma); the kernel issues NO MFMA:
                 # it is bound by the FP32 vector ALU, whose peak equals the dense f32 MFMA peak (157.3 TFLOP/s)
