@@ -720,3 +720,24 @@ def test_workspace_is_validated(rclib):
     assert b"workspace" in rclib.rc_last_error_string()
     for b in (surf, arr, ws):
         b.free()
+
+
+@pytest.mark.parametrize("mode,extra", [("bands", ["--gather", "rgba8"]), ("bands", []), ("frames", ["--sequence"])])
+def test_bench_two_ranks_share_one_gpu(mode, extra):
+    """bench.py's N>1 launch contract with two ranks on this one GPU (gloo instead of RCCL, both ranks
+    on device 0): one JSON line from rank 0; in bands mode the gathered frame equals the whole frame."""
+    import json, socket, sys
+    s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
+    env = dict(os.environ, RC_BENCH_BACKEND="gloo", RC_BENCH_SHARE_GPU="1")
+    r = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2",
+                        "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.join(ROOT, "bench.py"),
+                        "--gpus", "2", "--steps", "6", "--warmup", "2", "--mode", mode, "--config", "c2_1920x1080_n64",
+                        "--no-clock-ramp"] + extra, capture_output=True, text=True, timeout=400, env=env)
+    assert r.returncode == 0, r.stderr[-3000:]
+    lines = [l for l in r.stdout.splitlines() if l.strip()]
+    assert len(lines) == 1, r.stdout
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 2 and d["steps"] == 6 and len(d["per_rank_step_ms"]) == 2
+    assert d["scaling"] == ("strong" if mode == "bands" else "weak")
+    if mode == "bands":
+        assert d["gather_check"] is True
