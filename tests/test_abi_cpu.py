@@ -134,3 +134,15 @@ def test_sequence_camera_is_float_exact_and_periodic():
         p, r = configs.sequence_camera(f)
         assert all(float(np.float32(v)) == v for v in p + r)
         assert r[2] == 0.0 and p[2] == 20.0
+
+
+def test_header_is_plain_c99(tmp_path):
+    """include/rc_abi.h and the C example compile as strict C99 (the ABI is C, not C++) and link
+    against the library; nothing is run here."""
+    import os
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    exe = str(tmp_path / "render_frame")
+    subprocess.run(["gcc", "-std=c99", "-pedantic", "-Wall", "-Wextra", "-Werror", "-I" + os.path.join(root, "include"),
+                    os.path.join(root, "examples", "render_frame.c"), "-L" + os.path.dirname(abi.LIB_PATH), "-lrc_hip",
+                    "-Wl,-rpath," + os.path.dirname(abi.LIB_PATH), "-o", exe], check=True, capture_output=True)
+    assert os.path.exists(exe)

@@ -741,3 +741,24 @@ def test_bench_two_ranks_share_one_gpu(mode, extra):
     assert d["scaling"] == ("strong" if mode == "bands" else "weak")
     if mode == "bands":
         assert d["gather_check"] is True
+
+
+def test_c_example_renders_the_reference_frame(oracle, tmp_path):
+    """examples/render_frame.c (C99, context API): the reference's own window size and sphere count;
+    its PPM equals the oracle's frame."""
+    exe = str(tmp_path / "render_frame")
+    libdir = os.path.join(ROOT, "cudaraytracing_amd")
+    subprocess.run(["gcc", "-std=c99", "-I" + os.path.join(ROOT, "include"), os.path.join(ROOT, "examples", "render_frame.c"),
+                    "-L" + libdir, "-lrc_hip", "-Wl,-rpath," + libdir, "-o", exe], check=True, capture_output=True)
+    out = tmp_path / "ref.ppm"
+    r = subprocess.run([exe, str(out)], capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, r.stdout + r.stderr
+    w, h, n = 1280, 768, 512
+    pos, rad, col = oracle.generate_scene(n, 0)
+    cam = oracle.camera_data((0, 0, 20), (0, 0, 0), w, h)
+    want = oracle.render(pos, rad, col, cam, w, h)
+    assert f"{int(want[..., :3].any(axis=2).sum())} lit pixels" in r.stdout
+    head = f"P6\n{w} {h}\n255\n".encode()
+    data = out.read_bytes()
+    img = np.frombuffer(data[len(head):], np.uint8).reshape(h, w, 3)
+    assert np.array_equal(img, oracle.to_rgba8(want, flip=True)[..., :3])
