@@ -26,7 +26,6 @@ import os
 import sys
 import time
 
-import numpy as np
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
