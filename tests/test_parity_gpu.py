@@ -385,7 +385,6 @@ def test_full_size_golden_hashes(oracle, golden, name):
     bits = got.view(np.uint32)
     for s in fx["samples"]:
         assert bits[s[1], s[0]].tolist() == s[2:6]
-    import hashlib  # noqa: F401  (rgba8 hash uses the oracle's word hash over a flat view)
     flat = np.ascontiguousarray(rgba8).view(np.uint32).reshape(1, -1)
     scr = oracle.Screen(flat.ctypes.data, flat.shape[1] // 4, 1, flat.shape[1] * 4)
     assert f"{int(oracle.load().rco_fnv1a64_words(C.byref(scr), oracle.FNV_BASIS)):016x}" == fx["rgba8_flip_fnv"]
