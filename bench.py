@@ -58,6 +58,8 @@ def parse():
                          "(reported as end_to_end, never as value)")
     ap.add_argument("--graph", action="store_true",
                     help="also capture the K steps into one HIP graph and time its replay (reported as graph_replay, never as value)")
+    ap.add_argument("--no-extras", action="store_true",
+                    help="only the headline measurement: no culled_variant / display_conversion legs (for profiling runs)")
     ap.add_argument("--no-cpu", action="store_true", help="skip the cpu_baseline leg")
     ap.add_argument("--no-clock-ramp", action="store_true",
                     help="do not extend the untimed warm-up until the GPU has reached its steady clock")
@@ -356,7 +358,7 @@ def main():
     # Secondary measurement (N=1, default variant only): the opt-in tile-culling variant on the same
     # workload.  It is NOT `value`: it no longer performs one test per (pixel, sphere) pair.
     culled = None
-    if world == 1 and args.variant == "tiled" and args.mode == "frames":
+    if world == 1 and args.variant == "tiled" and args.mode == "frames" and not args.no_extras:
         copts = abi.RcOpts.from_buffer_copy(bytes(opts))
         copts.ext = opts.ext
         copts.variant = abi.VARIANT_CULLED
@@ -388,7 +390,7 @@ def main():
     # (DXManager.cpp:134,299,328), standalone (rc_to_rgba8: 16 B read + 4 B written per pixel,
     # HBM-bound) and fused into the draw kernel as a second surface (+4 B written per pixel).
     display = None
-    if world == 1 and args.variant == "tiled" and args.mode == "frames" and not args.sequence:
+    if world == 1 and args.variant == "tiled" and args.mode == "frames" and not args.sequence and not args.no_extras:
         out8 = torch.empty((rows, w), dtype=torch.int32, device="cuda")
         def timed(fn):
             for i in range(max(args.warmup, 3)):

@@ -8,7 +8,7 @@ ROOT=$(pwd)
 OUT=$ROOT/gpurun_out/prof_$TAG
 mkdir -p "$OUT"
 export TMPDIR=/tmp
-BENCH="python3 $ROOT/bench.py --steps 30 --warmup 5 --no-cpu --variant $VARIANT"
+BENCH="python3 $ROOT/bench.py --steps 30 --warmup 5 --no-cpu --no-extras --variant $VARIANT"
 cd /tmp
 timeout -s KILL 180 rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/trace" -- $BENCH > "$OUT/trace.log" 2>&1 || { echo "trace failed"; tail -5 "$OUT/trace.log"; exit 1; }
 i=0
