@@ -99,6 +99,7 @@ SYMBOLS = {
     "rc_event_create": (C.c_int, [C.POINTER(C.c_void_p)]),
     "rc_event_record": (C.c_int, [C.c_void_p, C.c_void_p]),
     "rc_event_elapsed_ms": (C.c_int, [C.c_void_p, C.c_void_p, C.POINTER(C.c_float)]),
+    "rc_event_wait": (C.c_int, [C.c_void_p]),
     "rc_event_destroy": (C.c_int, [C.c_void_p]),
     "rc_camera_data": (None, [C.POINTER(RcVec3), C.POINTER(RcVec3), C.c_int, C.c_int, C.POINTER(RcCamera)]),
     "rc_handle_input": (C.c_int, [C.POINTER(RcVec3), C.POINTER(RcVec3), C.c_float, C.c_float, C.c_float, C.POINTER(RcInput)]),

@@ -6,7 +6,7 @@
 // one of two device surfaces while the previous frame is still being read back to pinned host
 // memory on a second stream; the host only waits when it actually collects a frame.
 //
-//   FramePipeline pipe(rtk_scene, width, height, /*rgba8=*/true);
+//   FramePipeline pipe(width, height, /*rgba8=*/true);
 //   for (f ...) { scene.cam = ...; pipe.Submit(scene); if (f) use(pipe.Collect()); }
 //   use(pipe.Collect());
 #pragma once
@@ -24,29 +24,22 @@ public:
     // (4 B/pixel) crosses PCIe; false: the float surface (16 B/pixel) is read back.
     FramePipeline(int width, int height, bool rgba8) : w_(width), h_(height), rgba8_(rgba8)
     {
-        check(rc_stream_create(&render_), "rc_stream_create");
-        check(rc_stream_create(&copy_), "rc_stream_create");
-        for (int i = 0; i < 2; i++) {
-            check(rc_malloc_pitch(&surf_[i], &pitch_, (size_t)w_ * 16, (size_t)h_), "rc_malloc_pitch");
-            if (rgba8_) check(rc_malloc(&dev8_[i], (size_t)w_ * 4 * h_), "rc_malloc(rgba8)");
-            check(rc_host_alloc(&host_[i], frame_bytes()), "rc_host_alloc");
-            check(rc_event_create(&rendered_[i]), "rc_event_create");
-            check(rc_event_create(&copied_[i]), "rc_event_create");
+        try {
+            check(rc_stream_create(&render_), "rc_stream_create");
+            check(rc_stream_create(&copy_), "rc_stream_create");
+            for (int i = 0; i < 2; i++) {
+                check(rc_malloc_pitch(&surf_[i], &pitch_, (size_t)w_ * 16, (size_t)h_), "rc_malloc_pitch");
+                if (rgba8_) check(rc_malloc(&dev8_[i], (size_t)w_ * 4 * h_), "rc_malloc(rgba8)");
+                check(rc_host_alloc(&host_[i], frame_bytes()), "rc_host_alloc");
+                check(rc_event_create(&rendered_[i]), "rc_event_create");
+                check(rc_event_create(&copied_[i]), "rc_event_create");
+            }
+        } catch (...) {
+            Release();          // a constructor that throws runs no destructor
+            throw;
         }
     }
-    ~FramePipeline()
-    {
-        rc_sync(nullptr);
-        for (int i = 0; i < 2; i++) {
-            rc_free(surf_[i]);
-            if (dev8_[i]) rc_free(dev8_[i]);
-            rc_host_free(host_[i]);
-            rc_event_destroy(rendered_[i]);
-            rc_event_destroy(copied_[i]);
-        }
-        rc_stream_destroy(render_);
-        rc_stream_destroy(copy_);
-    }
+    ~FramePipeline() { Release(); }
     FramePipeline(const FramePipeline &) = delete;
     FramePipeline &operator=(const FramePipeline &) = delete;
 
@@ -85,13 +78,28 @@ public:
     {
         if (in_flight_ == 0) throw std::logic_error("FramePipeline: nothing to collect");
         const int b = (in_flight_ == 2) ? next_ : (next_ ^ 1);
-        float ms;
-        check(rc_event_elapsed_ms(rendered_[b], copied_[b], &ms), "rc_event_elapsed_ms");   // waits for the copy
+        check(rc_event_wait(copied_[b]), "rc_event_wait");
         in_flight_--;
         return host_[b];
     }
 
 private:
+    void Release()
+    {
+        rc_sync(nullptr);
+        for (int i = 0; i < 2; i++) {
+            if (surf_[i]) rc_free(surf_[i]);
+            if (dev8_[i]) rc_free(dev8_[i]);
+            if (host_[i]) rc_host_free(host_[i]);
+            if (rendered_[i]) rc_event_destroy(rendered_[i]);
+            if (copied_[i]) rc_event_destroy(copied_[i]);
+            surf_[i] = dev8_[i] = host_[i] = rendered_[i] = copied_[i] = nullptr;
+        }
+        if (render_) rc_stream_destroy(render_);
+        if (copy_) rc_stream_destroy(copy_);
+        render_ = copy_ = nullptr;
+    }
+
     int w_, h_;
     bool rgba8_;
     size_t pitch_ = 0;

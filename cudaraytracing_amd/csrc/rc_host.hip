@@ -530,6 +530,12 @@ extern "C" int rc_event_elapsed_ms(void *start, void *stop, float *ms)
     return RC_OK;
 }
 
+extern "C" int rc_event_wait(void *event)
+{
+    RC_HIP(hipEventSynchronize(static_cast<hipEvent_t>(event)));
+    return RC_OK;
+}
+
 extern "C" int rc_event_destroy(void *event)
 {
     RC_HIP(hipEventDestroy(static_cast<hipEvent_t>(event)));

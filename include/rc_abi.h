@@ -204,6 +204,7 @@ int rc_graph_destroy(void *graph_exec);
 int rc_event_create(void **event);
 int rc_event_record(void *event, void *stream);
 int rc_event_elapsed_ms(void *start, void *stop, float *ms); /* waits for `stop` */
+int rc_event_wait(void *event);                              /* blocks the host until `event` has happened */
 int rc_event_destroy(void *event);
 
 /* Camera.h:43-55,71-91,101-112: position + Euler rotation -> CameraData */
