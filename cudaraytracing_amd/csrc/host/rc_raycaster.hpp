@@ -77,10 +77,11 @@ public:
         void *d8 = nullptr;
         const size_t pitch8 = (size_t)screen.width * 4;
         check(rc_malloc(&d8, pitch8 * screen.height), "rc_malloc(rgba8)");
-        check(rc_to_rgba8(&screen, d8, pitch8, 1, nullptr), "rc_to_rgba8");
         std::vector<uint8_t> host(pitch8 * screen.height);
-        check(rc_download_2d(host.data(), pitch8, d8, pitch8, pitch8, (size_t)screen.height, nullptr), "rc_download_2d");
-        rc_free(d8);
+        int rc = rc_to_rgba8(&screen, d8, pitch8, 1, nullptr);
+        if (rc == RC_OK) rc = rc_download_2d(host.data(), pitch8, d8, pitch8, pitch8, (size_t)screen.height, nullptr);
+        rc_free(d8);                                      // also when a step above failed
+        check(rc, "rc_to_rgba8 / rc_download_2d");
         check(rc_write_ppm(path, host.data(), pitch8, screen.width, screen.height), "rc_write_ppm");
     }
 
