@@ -177,6 +177,16 @@ def test_filter_soak_tiled_vs_literal_on_device(oracle):
         else:
             rot = (float(rng.uniform(-3.2, 3.2)), float(rng.uniform(-3.2, 3.2)), 0.0)
         cam = oracle.camera_data(cpos, rot, w, h)
+        if it % 4 == 3:
+            # cameras the reference's Camera class cannot produce but its CameraData struct can carry:
+            # other fields of view and aspects, basis vectors that are neither unit nor orthogonal
+            from gpu_util import to_rc_camera
+            cam = to_rc_camera(cam)
+            cam.fov = float(10.0 ** rng.uniform(-2, 0.49))
+            cam.aspect = float(10.0 ** rng.uniform(-0.7, 0.7))
+            for v in (cam.forward, cam.up, cam.right):
+                sc_, sh_ = float(10.0 ** rng.uniform(-0.3, 0.3)), rng.normal(size=3) * 0.05
+                v.x, v.y, v.z = v.x * sc_ + float(sh_[0]), v.y * sc_ + float(sh_[1]), v.z * sc_ + float(sh_[2])
         scene = GpuScene(pos, rad, col)
         want = pixels(gpu_render(pos, rad, col, cam, w, h, variant=abi.VARIANT_LITERAL, scene=scene), w)
         got = pixels(gpu_render(pos, rad, col, cam, w, h, variant=variants[it % 4], scene=scene), w)
