@@ -365,8 +365,8 @@ def main():
         # records built once per frame in a caller workspace (16 bytes per sphere); below ~1000
         # spheres the extra launch costs more than every workgroup building its own
         use_ws = n >= 1024
-        if use_ws:
-            wsp = torch.empty((n, 4), dtype=torch.float32, device="cuda")
+        if use_ws:       # records + per-bin sphere lists
+            wsp = torch.empty((lib.rc_workspace_bytes_frame(n, w, rows) + 3) // 4, dtype=torch.float32, device="cuda")
             copts.workspace, copts.workspace_bytes = wsp.data_ptr(), wsp.numel() * 4
         for i in range(max(args.warmup, 3)):
             abi.check(lib.rc_render(C.byref(screen), C.byref(scene), C.byref(copts)), "rc_render")
@@ -380,7 +380,7 @@ def main():
         abi.check(lib.rc_event_elapsed_ms(ev0, ev1, C.byref(cms)))
         cms = cms.value / args.steps
         culled = {"variant": "culled (RC_VARIANT_CULLED, opt-in): interval tests per workgroup tile, then per wave tile, in place of the per-pixel loop; "
-                             + ("records built once per frame in rc_opts.workspace; " if use_ws else "") +
+                             + ("records and per-bin sphere lists built once per frame in rc_opts.workspace; " if use_ws else "") +
                              "bit-identical surfaces, not one test per (pixel, sphere) pair",
                   "value": w * h / (cms * 1e-3) / 1e6, "unit": "Mrays/s", "frame_ms": cms,
                   "roofline": {"bound": "hbm", "achieved": 16.0 * w * h / (cms * 1e-3) / 1e9, "peak": HBM_PEAK_GBS,

@@ -73,6 +73,7 @@ assert C.sizeof(RcOpts) == 72 and RcOpts.workspace.offset == 56 and C.sizeof(RcI
 SYMBOLS = {
     "rc_render": (C.c_int, [C.POINTER(RcScreen), C.POINTER(RcScene), C.POINTER(RcOpts)]),
     "rc_workspace_bytes": (C.c_size_t, [C.c_int]),
+    "rc_workspace_bytes_frame": (C.c_size_t, [C.c_int, C.c_int, C.c_int]),
     "rc_prepare": (C.c_int, [C.c_int, C.c_int, C.c_float]),
     "rc_to_rgba8": (C.c_int, [C.POINTER(RcScreen), C.c_void_p, C.c_size_t, C.c_int, C.c_void_p]),
     "rc_device_count": (C.c_int, [C.POINTER(C.c_int)]),

@@ -36,6 +36,7 @@ static_assert(offsetof(rc_screen, width) == 8 && offsetof(rc_screen, height) == 
 namespace {
 
 thread_local char g_err[256] = "";
+constexpr int kMinBinnedSpheres = 2048;  // below this the binning launch costs more than it saves (measured)
 constexpr int kMaxDim = 65536;      // frame width / height limit (keeps every grid within range)
 
 int rc_fail_hip(hipError_t e, const char *what)
@@ -275,6 +276,12 @@ extern "C" int rc_render(const rc_screen *screen, const rc_scene *scene, const r
         hipError_t er = rc_launch_records(a, records, static_cast<hipStream_t>(o.stream));
         if (er != hipSuccess) return rc_fail_hip(er, "record kernel launch");
         a.records = records;
+        // level 0 (per-bin sphere lists) when the workspace also has room for it
+        const size_t rec_bytes = (rc_workspace_bytes(a.n) + 255) & ~(size_t)255;
+        if (o.workspace_bytes > rec_bytes && a.n >= kMinBinnedSpheres) {
+            a.bins = static_cast<const unsigned char *>(o.workspace) + rec_bytes;
+            a.bins_bytes = o.workspace_bytes - rec_bytes;
+        }
     }
     hipError_t e = rc_launch_draw(a, kv, cus, static_cast<hipStream_t>(o.stream));
     if (e != hipSuccess) return rc_fail_hip(e, "draw kernel launch");
@@ -284,6 +291,17 @@ extern "C" int rc_render(const rc_screen *screen, const rc_scene *scene, const r
 extern "C" size_t rc_workspace_bytes(int sphere_num)
 {
     return sphere_num > 0 ? (size_t)sphere_num * 16 : 0;
+}
+
+extern "C" size_t rc_workspace_bytes_frame(int sphere_num, int width, int height)
+{
+    if (sphere_num <= 0 || width <= 0 || height <= 0) return 0;
+    const size_t rec_bytes = (rc_workspace_bytes(sphere_num) + 255) & ~(size_t)255;
+    if (sphere_num > 65535) return rec_bytes;                   // lists hold 16-bit indices
+    // smallest workgroup tile the culled variant uses is 32 x 16 pixels; a bin is 4 x 4 of them
+    const size_t bins = (size_t)((width + 127) / 128) * (size_t)((height + 63) / 64);
+    const size_t q = (((size_t)sphere_num + 3) / 4 + 7) & ~(size_t)7;
+    return rec_bytes + bins * (16 + 8 * q);
 }
 
 extern "C" int rc_prepare(int width, int full_height, float fov)

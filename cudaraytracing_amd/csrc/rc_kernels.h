@@ -44,9 +44,12 @@ struct RcKernArgs {
     float specular;
     // culled variant: sphere records built once per frame by rc_launch_records (else NULL)
     const float4 *records;   // [n] {alpha, gamma, beta, always ? 1 : 0}
+    const unsigned char *bins; // culled variant, level 0: per-bin sphere lists (else NULL); bins_bytes available
+    size_t bins_bytes;
     // filled in by the tiled launcher
     int lds_cap;             // spheres per LDS chunk (multiple of 32)
     int tiles_x, tiles_y;    // workgroup tiles covering the surface
+    int bins_x, bin_q, bin_stride; // bins per row, entries per list segment, bytes per bin
 };
 
 hipError_t rc_launch_draw(const RcKernArgs &a, int variant, int compute_units, hipStream_t stream);

@@ -363,14 +363,18 @@ constexpr int kGroupsPerBlock = kBlockSpheres / kGroup;
 __host__ __device__ constexpr size_t rc_lds_bytes(int cap) { return (size_t)cap * 12 + (size_t)cap + 16; }
 // The culled variant appends: float wg_bounds[4][8] (per-wave tile bounds), ushort list[cap]
 // (indices of the spheres that pass the workgroup-tile test, one segment of cap/4 per wave),
-// int count[4] (entries per segment).
-__host__ __device__ constexpr size_t rc_lds_bytes_cull(int cap) { return rc_lds_bytes(cap) + 128 + (size_t)cap * 2 + 16; }
+// int count[4] (entries per segment) and, with bin lists, int id[cap] (scene index of each slot's sphere).
+__host__ __device__ constexpr size_t rc_lds_bytes_cull(int cap, bool with_ids)
+{
+    return rc_lds_bytes(cap) + 128 + (size_t)cap * 2 + 16 + (with_ids ? (size_t)cap * 4 : 0);
+}
 
 // One sphere the tile-level test could not rule out: per-pixel filter, then the exact test if
-// some lane still flags it.  j is wave-uniform (index inside the LDS chunk).
+// some lane still flags it.  j (slot inside the LDS chunk) and sphere (its index in the scene)
+// are wave-uniform.
 template <int P>
 __device__ __forceinline__ void rc_visit_sphere(const RcKernArgs &a, const float *rec, const unsigned char *flagb,
-                                                int j, int base, bool lane_forced,
+                                                int j, int sphere, bool lane_forced,
                                                 const float (&fa)[P], float fb, const float (&len)[P],
                                                 const float (&dx)[P], const float (&dy)[P], const float (&dz)[P],
                                                 float (&minDist)[P], int (&idx)[P])
@@ -386,11 +390,11 @@ __device__ __forceinline__ void rc_visit_sphere(const RcKernArgs &a, const float
         any |= pm[p];
     }
     if (any == 0ull) return;
-    const RcExactSphere e = rc_exact_sphere(a, base + j);
+    const RcExactSphere e = rc_exact_sphere(a, sphere);
     // the exact test only for pixel columns in which some lane still flags the sphere
 #pragma unroll
     for (int p = 0; p < P; p++)
-        if (pm[p] != 0ull) rc_exact_test(e, dx[p], dy[p], dz[p], base + j, minDist[p], idx[p]);
+        if (pm[p] != 0ull) rc_exact_test(e, dx[p], dy[p], dz[p], sphere, minDist[p], idx[p]);
 }
 
 __device__ __forceinline__ float rc_wave_min(float v)
@@ -628,7 +632,7 @@ __device__ __forceinline__ void rc_shadow_pass(const RcKernArgs &a, char *lds,
     }
 }
 
-template <int P, bool EXT, bool CULL>
+template <int P, bool EXT, bool CULL, bool BINS>
 __device__ __forceinline__ void rc_tiled_body(const RcKernArgs &a, char *lds)
 {
     constexpr int TW = 8 * P;   // wave tile width in pixels
@@ -702,6 +706,20 @@ __device__ __forceinline__ void rc_tiled_body(const RcKernArgs &a, char *lds)
         float *s_wgb = reinterpret_cast<float *>(lds + rc_lds_bytes(cap));
         unsigned short *s_list = reinterpret_cast<unsigned short *>(lds + rc_lds_bytes(cap) + 128);
         int *s_cnt = reinterpret_cast<int *>(lds + rc_lds_bytes(cap) + 128 + (size_t)cap * 2);
+        int *s_id = reinterpret_cast<int *>(lds + rc_lds_bytes(cap) + 128 + (size_t)cap * 2 + 16);
+        // Level 0 (optional): the spheres that can touch this workgroup tile's bin (4 x 4 workgroup
+        // tiles), listed in ascending index by rc_bin_spheres as four segments.
+        int total = a.n, bc0 = 0, bc1 = 0, bc2 = 0;
+        const unsigned short *bsegs = nullptr;
+        if (CULL && BINS) {
+            const int tile = blockIdx.x;
+            const int tyi = tile / a.tiles_x, txi = tile - tyi * a.tiles_x;
+            const unsigned char *bin = a.bins + (size_t)((tyi >> 2) * a.bins_x + (txi >> 2)) * a.bin_stride;
+            const int *bc = reinterpret_cast<const int *>(bin);
+            bc0 = bc[0]; bc1 = bc[1]; bc2 = bc[2];
+            total = bc0 + bc1 + bc2 + bc[3];
+            bsegs = reinterpret_cast<const unsigned short *>(bin + 16);
+        }
         float wa_lo = 0.0f, wa_hi = 0.0f, wb_lo = 0.0f, wb_hi = 0.0f, wa_abs = 0.0f, wb_abs = 0.0f, wlen_min = 0.0f;
         bool wg_forced = false;
         if (CULL) {
@@ -724,8 +742,8 @@ __device__ __forceinline__ void rc_tiled_body(const RcKernArgs &a, char *lds)
             wb_abs = fmaxf(fabsf(wb_lo), fabsf(wb_hi));
         }
 
-        for (int base = 0; base < a.n; base += cap) {
-            const int cn = min(a.n - base, cap);
+        for (int base = 0; base < total; base += cap) {
+            const int cn = min(total - base, cap);
             const int cnb = (cn + kBlockSpheres - 1) & ~(kBlockSpheres - 1);   // whole blocks
             if (CULL) {
                 // Records as in the brute-force variant, but wave w builds the contiguous range
@@ -745,11 +763,18 @@ __device__ __forceinline__ void rc_tiled_body(const RcKernArgs &a, char *lds)
                         RcRecord r;
                         r.alpha = kNever; r.gamma = 0.0f; r.beta = 0.0f; r.always = false;
                         if (j < cn) {
-                            if (a.records) {           // built once per frame by rc_build_records
-                                const float4 v = a.records[base + j];
+                            int sphere = base + j;
+                            if (BINS) {                // entry base + j of the bin's four segments
+                                int e = sphere, seg = 0;
+                                if (e >= bc0) { e -= bc0; seg = 1; if (e >= bc1) { e -= bc1; seg = 2; if (e >= bc2) { e -= bc2; seg = 3; } } }
+                                sphere = bsegs[seg * a.bin_q + e];
+                            }
+                            if (BINS) s_id[j] = sphere;
+                            if (BINS || a.records) {   // built once per frame by rc_build_records
+                                const float4 v = a.records[sphere];
                                 r.alpha = v.x; r.gamma = v.y; r.beta = v.z; r.always = (v.w != 0.0f);
                             } else {
-                                r = rc_prepass_sphere(a, base + j);
+                                r = rc_prepass_sphere(a, sphere);
                             }
                         }
                         float *g = rec + (j >> 2) * 12 + (j & 3);
@@ -811,7 +836,7 @@ __device__ __forceinline__ void rc_tiled_body(const RcKernArgs &a, char *lds)
                             const int bit = __builtin_ctzll(cand_mask);
                             cand_mask &= cand_mask - 1ull;
                             const int j = __builtin_amdgcn_readlane(jl, bit);
-                            rc_visit_sphere<P>(a, rec, flagb, j, base, lane_forced, fa, fb, len,
+                            rc_visit_sphere<P>(a, rec, flagb, j, BINS ? s_id[j] : base + j, lane_forced, fa, fb, len,
                                                dx, dy, dz, minDist, idx);
                         }
                     }
@@ -862,7 +887,7 @@ __device__ __forceinline__ void rc_tiled_body(const RcKernArgs &a, char *lds)
                     while (cand_mask != 0ull) {
                         const int bit = __builtin_ctzll(cand_mask);
                         cand_mask &= cand_mask - 1ull;
-                        rc_visit_sphere<P>(a, rec, flagb, blk * kBlockSpheres + bit, base, lane_forced, fa, fb, len,
+                        rc_visit_sphere<P>(a, rec, flagb, blk * kBlockSpheres + bit, base + blk * kBlockSpheres + bit, lane_forced, fa, fb, len,
                                            dx, dy, dz, minDist, idx);
                     }
                 }
@@ -909,11 +934,90 @@ __device__ __forceinline__ void rc_tiled_body(const RcKernArgs &a, char *lds)
 
 } // namespace
 
-template <int P, bool EXT, bool CULL>
+template <int P, bool EXT, bool CULL, bool BINS = false>
 __global__ __launch_bounds__(256, (EXT && P == 4) ? 4 : 1) void rc_draw_tiled(RcKernArgs a)
 {
     extern __shared__ __attribute__((aligned(16))) char rc_lds[];
-    rc_tiled_body<P, EXT, CULL>(a, rc_lds);
+    rc_tiled_body<P, EXT, CULL, BINS>(a, rc_lds);
+}
+
+// Level 0 of the culled variant (caller workspace): one workgroup per bin of 4 x 4 workgroup tiles
+// lists, in ascending index, the spheres whose filter value can reach |q| somewhere in the bin.
+// Bounds of the bin: a and b ranges by a scan of the sine tables over the bin's columns and rows (the
+// values the lanes will use, clamped columns/rows included); a lower bound of len = |F + aR + bU| from
+// convexity: |q|^2 >= |q0|^2 + grad.(a - a0, b - b0) >= |q0|^2 - |2 q0.R| ha - |2 q0.U| hb at the
+// centre (a0, b0) with half-widths ha, hb, lowered by 2^-18 of the squared magnitudes for the float
+// evaluation and by 2^-20 Q for the difference between the reference's float |q| and the real one.
+// If that bound cannot exclude that some lane of the bin is "forced" (Q > 4 len, len out of range),
+// or the camera is out of range, the bin lists every sphere.
+__global__ __launch_bounds__(256) void rc_bin_spheres(RcKernArgs a, int tile_w, unsigned char *bins)
+{
+    __shared__ float s_red[4][4];
+    __shared__ int s_nan[4];
+    const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+    const int by = blockIdx.x / a.bins_x, bx = blockIdx.x - by * a.bins_x;
+    const int x0 = bx * 4 * tile_w, x1 = min(a.width, x0 + 4 * tile_w);
+    const int y0 = by * 64, y1 = min(a.rows, y0 + 64);
+    float alo = __builtin_inff(), ahi = -__builtin_inff(), blo = __builtin_inff(), bhi = -__builtin_inff();
+    bool nan_seen = false;
+    for (int x = x0 + tid; x < x1; x += 256) {
+        const float v = a.sin_x[x] * a.aspect;
+        nan_seen = nan_seen || !(v == v);
+        alo = fminf(alo, v); ahi = fmaxf(ahi, v);
+    }
+    for (int y = y0 + tid; y < y1; y += 256) {
+        const float v = a.sin_y[y + a.y_offset];
+        nan_seen = nan_seen || !(v == v);
+        blo = fminf(blo, v); bhi = fmaxf(bhi, v);
+    }
+    alo = rc_wave_min(alo); ahi = rc_wave_max(ahi); blo = rc_wave_min(blo); bhi = rc_wave_max(bhi);
+    const bool any_nan = __builtin_amdgcn_ballot_w64(nan_seen) != 0ull;
+    if (lane == 0) {
+        s_red[wave][0] = alo; s_red[wave][1] = ahi; s_red[wave][2] = blo; s_red[wave][3] = bhi;
+        s_nan[wave] = any_nan ? 1 : 0;
+    }
+    __syncthreads();
+    bool forced = (a.cam_ok == 0);
+#pragma unroll
+    for (int k = 0; k < 4; k++) {
+        alo = fminf(alo, s_red[k][0]); ahi = fmaxf(ahi, s_red[k][1]);
+        blo = fminf(blo, s_red[k][2]); bhi = fmaxf(bhi, s_red[k][3]);
+        forced = forced || (s_nan[k] != 0);
+    }
+    const float a_abs = fmaxf(fabsf(alo), fabsf(ahi)), b_abs = fmaxf(fabsf(blo), fabsf(bhi));
+    const float a0 = 0.5f * (alo + ahi), b0 = 0.5f * (blo + bhi);
+    const float ha = fmaxf(ahi - a0, a0 - alo) * (1.0f + 0x1p-20f), hb = fmaxf(bhi - b0, b0 - blo) * (1.0f + 0x1p-20f);
+    const float qx = __builtin_fmaf(b0, a.ux, __builtin_fmaf(a0, a.rx, a.fx));
+    const float qy = __builtin_fmaf(b0, a.uy, __builtin_fmaf(a0, a.ry, a.fy));
+    const float qz = __builtin_fmaf(b0, a.uz, __builtin_fmaf(a0, a.rz, a.fz));
+    const float l2 = __builtin_fmaf(qz, qz, __builtin_fmaf(qy, qy, qx * qx));
+    const float ga = 2.0f * fabsf(__builtin_fmaf(qz, a.rz, __builtin_fmaf(qy, a.ry, qx * a.rx)));
+    const float gb = 2.0f * fabsf(__builtin_fmaf(qz, a.uz, __builtin_fmaf(qy, a.uy, qx * a.ux)));
+    const float Q = a.nF + a_abs * a.nR + b_abs * a.nU;              // >= every lane's Q (same expression, monotone)
+    const float lb2 = (l2 - (ga * ha + gb * hb)) - 0x1p-18f * (Q * Q + (ga * ha + gb * hb));
+    float lb = __builtin_amdgcn_sqrtf(fmaxf(lb2, 0.0f)) * (1.0f - 0x1p-20f) - 0x1p-20f * Q;
+    // no lane of the bin may be "forced" unless the bin is: Q_lane <= Q <= 4 lb <= 4 len_lane etc.
+    if (!(lb2 > 0.0f) || !(lb > 0x1p-19f) || !(Q < 0x1p19f) || !(Q <= 4.0f * lb)) forced = true;
+
+    unsigned short *segs = reinterpret_cast<unsigned short *>(bins + (size_t)blockIdx.x * a.bin_stride + 16);
+    int *counts = reinterpret_cast<int *>(bins + (size_t)blockIdx.x * a.bin_stride);
+    const int Qb = a.bin_q;
+    int count = 0;
+    for (int k0 = 0; k0 < Qb; k0 += 64) {
+        const int jj = k0 + lane;
+        const int j = wave * Qb + jj;
+        bool pass = false;
+        if (jj < Qb && j < a.n) {
+            const float4 v = a.records[j];
+            const float tmax = (v.x + fmaxf(blo * v.y, bhi * v.y)) + fmaxf(alo * v.z, ahi * v.z);
+            const float mag = (fabsf(v.x) + b_abs * fabsf(v.y)) + a_abs * fabsf(v.z);
+            pass = forced || (v.w != 0.0f) || !(tmax + 0x1p-20f * mag < lb);
+        }
+        const unsigned long long mask = __builtin_amdgcn_ballot_w64(pass);
+        if (pass) segs[wave * Qb + count + __builtin_popcountll(mask & ((1ull << lane) - 1ull))] = (unsigned short)j;
+        count += __builtin_popcountll(mask);
+    }
+    if (lane == 0) counts[wave] = count;
 }
 
 // Sphere records of one frame for the culled variant with a caller workspace: the same
@@ -962,15 +1066,32 @@ static hipError_t rc_launch_tiled(RcKernArgs a, hipStream_t stream)
     a.tiles_x = (a.width + 16 * P - 1) / (16 * P);
     a.tiles_y = (a.rows + 15) / 16;
     const unsigned grid = (unsigned)rc_tile_count<P>(a);
+    if (a.cull && a.bins) {
+        // level 0: bins of 4 x 4 workgroup tiles; layout fixed here because it depends on P
+        a.bins_x = (a.tiles_x + 3) / 4;
+        const int bins_y = (a.tiles_y + 3) / 4;
+        a.bin_q = (((a.n + 3) / 4) + 7) & ~7;
+        a.bin_stride = 16 + 8 * a.bin_q;
+        if ((size_t)a.bins_x * bins_y * a.bin_stride > a.bins_bytes || a.n > 65535 || !a.records) {
+            a.bins = nullptr;                      // workspace too small for this tiling: level 0 is skipped
+        } else {
+            hipLaunchKernelGGL(rc_bin_spheres, dim3((unsigned)(a.bins_x * bins_y)), dim3(256), 0, stream, a, 16 * P,
+                               const_cast<unsigned char *>(a.bins));
+            hipError_t eb = hipGetLastError();
+            if (eb != hipSuccess) return eb;
+        }
+    }
     if (a.ext_mode) {
         if constexpr (P <= 4) {
-            if (a.cull) hipLaunchKernelGGL((rc_draw_tiled<P, true, true>), dim3(grid), dim3(256), rc_lds_bytes_cull(a.lds_cap), stream, a);
+            if (a.cull && a.bins) hipLaunchKernelGGL((rc_draw_tiled<P, true, true, true>), dim3(grid), dim3(256), rc_lds_bytes_cull(a.lds_cap, true), stream, a);
+            else if (a.cull) hipLaunchKernelGGL((rc_draw_tiled<P, true, true>), dim3(grid), dim3(256), rc_lds_bytes_cull(a.lds_cap, false), stream, a);
             else hipLaunchKernelGGL((rc_draw_tiled<P, true, false>), dim3(grid), dim3(256), rc_lds_bytes(a.lds_cap), stream, a);
         } else {
             return hipErrorInvalidValue;           // EXT is built for <= 4 pixels per lane
         }
     } else {
-        if (a.cull) hipLaunchKernelGGL((rc_draw_tiled<P, false, true>), dim3(grid), dim3(256), rc_lds_bytes_cull(a.lds_cap), stream, a);
+        if (a.cull && a.bins) hipLaunchKernelGGL((rc_draw_tiled<P, false, true, true>), dim3(grid), dim3(256), rc_lds_bytes_cull(a.lds_cap, true), stream, a);
+        else if (a.cull) hipLaunchKernelGGL((rc_draw_tiled<P, false, true>), dim3(grid), dim3(256), rc_lds_bytes_cull(a.lds_cap, false), stream, a);
         else hipLaunchKernelGGL((rc_draw_tiled<P, false, false>), dim3(grid), dim3(256), rc_lds_bytes(a.lds_cap), stream, a);
     }
     return hipGetLastError();

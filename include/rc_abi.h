@@ -127,6 +127,10 @@ typedef struct rc_opts {
 
 /* bytes of rc_opts.workspace needed for a scene of sphere_num spheres (16 per sphere) */
 size_t rc_workspace_bytes(int sphere_num);
+/* bytes that additionally let RC_VARIANT_CULLED list, per bin of 4 x 4 workgroup tiles, the spheres
+ * that can touch the bin (a third small kernel), so that a workgroup walks its bin's list instead of
+ * the whole scene; for frames of this size.  A workspace between the two sizes gets the records only. */
+size_t rc_workspace_bytes_frame(int sphere_num, int width, int height);
 
 /* ---- the hot path ---------------------------------------------------------------------- */
 

@@ -65,8 +65,9 @@ def gpu_render(pos, rad, col, cam, width, height, variant=abi.VARIANT_AUTO, y_of
         opts.rgba8, opts.rgba8_pitch, opts.rgba8_flip = rgba.ptr.value, width * 4, 1 if flip else 0
     sc = gs.scene(cam)
     ws = None
-    if workspace:            # records built once per frame (culled variant)
-        ws = DeviceBuffer(max(lib.rc_workspace_bytes(gs.n), 16))
+    if workspace:            # culled variant: records once per frame; plus per-bin lists unless "records"
+        nbytes = lib.rc_workspace_bytes(gs.n) if workspace == "records" else lib.rc_workspace_bytes_frame(gs.n, width, height)
+        ws = DeviceBuffer(max(nbytes, 16))
         opts.workspace, opts.workspace_bytes = ws.ptr.value, ws.nbytes
     abi.check(lib.rc_render(C.byref(screen), C.byref(sc), C.byref(opts)), "rc_render")
     abi.check(lib.rc_sync(None), "rc_sync")

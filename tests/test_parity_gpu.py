@@ -161,6 +161,7 @@ def test_filter_soak_tiled_vs_literal_on_device(oracle):
     rng = np.random.default_rng(int(os.environ.get("RC_SOAK_SEED", "99")))
     w, h = 192, 104
     variants = [abi.VARIANT_TILED2, abi.VARIANT_TILED4, abi.VARIANT_TILED8, abi.VARIANT_CULLED]
+    with_bins = os.environ.get("RC_SOAK_BINS") == "1"     # culled variant with records + bin lists in a workspace
     for it in range(int(os.environ.get("RC_SOAK_SCENES", "600"))):
         n = int(rng.integers(1, int(os.environ.get("RC_SOAK_NMAX", "120"))))
         spread = 10.0 ** rng.uniform(-1, 2)
@@ -189,7 +190,10 @@ def test_filter_soak_tiled_vs_literal_on_device(oracle):
                 v.x, v.y, v.z = v.x * sc_ + float(sh_[0]), v.y * sc_ + float(sh_[1]), v.z * sc_ + float(sh_[2])
         scene = GpuScene(pos, rad, col)
         want = pixels(gpu_render(pos, rad, col, cam, w, h, variant=abi.VARIANT_LITERAL, scene=scene), w)
-        got = pixels(gpu_render(pos, rad, col, cam, w, h, variant=variants[it % 4], scene=scene), w)
+        if with_bins:
+            got = pixels(gpu_render(pos, rad, col, cam, w, h, variant=abi.VARIANT_CULLED, scene=scene, workspace=True), w)
+        else:
+            got = pixels(gpu_render(pos, rad, col, cam, w, h, variant=variants[it % 4], scene=scene), w)
         scene.free()
         assert_same_bits(got, want, f"soak {it}: n={n} cam={cpos} rot={rot} variant={variants[it % 4]}")
         if it % 5000 == 4999:
@@ -701,16 +705,28 @@ def test_context_api_end_to_end(oracle, rclib, tmp_path):
     assert rclib.rc_ctx_render(None, None) == abi.RC_EINVAL
 
 
-@pytest.mark.parametrize("w,h,n", [(333, 77, 5), (640, 480, 1024), (200, 120, 2049), (64, 48, 8200), (65, 17, 0)])
+@pytest.mark.parametrize("w,h,n", [(333, 77, 5), (640, 480, 1024), (200, 120, 2049), (700, 300, 3000), (64, 48, 8200), (65, 17, 0)])
 def test_culled_with_workspace_records(oracle, w, h, n):
     """RC_VARIANT_CULLED with rc_opts.workspace: the records come from the once-per-frame kernel
     instead of every workgroup's own prepass; same bits (REF and EXT)."""
     pos, rad, col = oracle.generate_scene(n, 17)
     cam = oracle.camera_data((0.4, -0.3, 19.0), (0.03, -0.06, 0), w, h)
     want = oracle.render(pos, rad, col, cam, w, h)
-    got = pixels(gpu_render(pos, rad, col, cam, w, h, variant=abi.VARIANT_CULLED, workspace=True), w)
-    assert_same_bits(got, want, f"culled+workspace {w}x{h} n={n}")
-    if n <= 2049:
+    for ws in ("records", True):
+        got = pixels(gpu_render(pos, rad, col, cam, w, h, variant=abi.VARIANT_CULLED, workspace=ws), w)
+        assert_same_bits(got, want, f"culled+workspace({ws}) {w}x{h} n={n}")
+    # cameras inside / hugging spheres and a wide field of view: bins that must list everything
+    for k, off in [(0, 0.5), (min(3, max(n - 1, 0)), 1.00001)]:
+        if n == 0:
+            break
+        cpos = tuple(float(v) for v in (pos[k] + np.array([0.6, 0.0, 0.8]) * rad[k] * off))
+        from gpu_util import to_rc_camera
+        cam2 = to_rc_camera(oracle.camera_data(cpos, (0.2, 0.4, 0), w, h))
+        cam2.fov = 2.9
+        want2 = pixels(gpu_render(pos, rad, col, cam2, w, h, variant=abi.VARIANT_LITERAL), w)
+        got2 = pixels(gpu_render(pos, rad, col, cam2, w, h, variant=abi.VARIANT_CULLED, workspace=True), w)
+        assert_same_bits(got2, want2, f"culled+bins camera near sphere {k} n={n}")
+    if n <= 3000:
         ext = _default_ext(oracle)
         want = oracle.render(pos, rad, col, cam, w, h, ext=ext)
         got = pixels(gpu_render(pos, rad, col, cam, w, h, variant=abi.VARIANT_CULLED, workspace=True, ext=ext), w)
