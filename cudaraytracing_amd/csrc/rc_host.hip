@@ -683,6 +683,8 @@ extern "C" const char *rc_version(void) { return "rc_hip 0.1 gfx950"; }
 struct rc_ctx {
     int device = 0;
     rc::RayTracingKernel rtk;
+    void *workspace = nullptr;       // for RC_VARIANT_CULLED: records + bin lists of the current scene / frame size
+    size_t workspace_bytes = 0;
 };
 
 namespace {
@@ -725,7 +727,11 @@ extern "C" int rc_ctx_create(rc_ctx **out, int device, int width, int height)
 extern "C" int rc_ctx_destroy(rc_ctx *ctx)
 {
     if (!ctx) return RC_OK;
-    int rc = rc_ctx_call(ctx, [](rc::RayTracingKernel &k) { k.Cleanup(); });
+    int rc = rc_ctx_call(ctx, [&](rc::RayTracingKernel &k) {
+        k.Cleanup();
+        if (ctx->workspace) rc_free(ctx->workspace);
+        ctx->workspace = nullptr;
+    });
     delete ctx;
     return rc;
 }
@@ -783,6 +789,24 @@ extern "C" int rc_ctx_render(rc_ctx *ctx, const rc_opts *opts)
 {
     return rc_ctx_call(ctx, [&](rc::RayTracingKernel &k) {
         if (!k.screen.surface) throw std::runtime_error("rc_ctx_render: no surface (call rc_surface_alloc)");
+        if (opts && opts->variant == RC_VARIANT_CULLED && !opts->workspace) {
+            // the context lends its own workspace (grown when the scene or the frame got bigger;
+            // the device is idle-waited before the old one is freed, frames may still read it)
+            const size_t need = rc_workspace_bytes_frame(k.sm.scene.sphere_num, k.screen.width, k.screen.height);
+            if (need > ctx->workspace_bytes) {
+                rc::check(rc_sync(nullptr), "rc_sync");
+                if (ctx->workspace) rc_free(ctx->workspace);
+                ctx->workspace = nullptr;
+                ctx->workspace_bytes = 0;
+                rc::check(rc_malloc(&ctx->workspace, need), "rc_malloc(workspace)");
+                ctx->workspace_bytes = need;
+            }
+            rc_opts o = *opts;
+            o.workspace = ctx->workspace;
+            o.workspace_bytes = ctx->workspace_bytes;
+            rc::check(rc_render(&k.screen, &k.sm.scene, &o), "rc_render");
+            return;
+        }
         rc::check(rc_render(&k.screen, &k.sm.scene, opts), "rc_render");
     });
 }

@@ -261,7 +261,9 @@ int rc_camera_set(rc_ctx *ctx, const rc_vec3 *position, const rc_vec3 *rotation)
 int rc_camera_input(rc_ctx *ctx, const rc_input *input, float dt);
 /* RegisterTexture's cudaMallocPitch + cudaMemset(1) (RayTracingKernel.cpp:93-94); pitch may be NULL */
 int rc_surface_alloc(rc_ctx *ctx, size_t *pitch);
-/* RayTracingKernel::Run's launch (RayTracingKernel.cpp:17); enqueue only, opts may be NULL */
+/* RayTracingKernel::Run's launch (RayTracingKernel.cpp:17); enqueue only, opts may be NULL.  With
+ * opts->variant == RC_VARIANT_CULLED and no opts->workspace the context lends one of its own, so
+ * renders of one context must then not overlap on different streams. */
 int rc_ctx_render(rc_ctx *ctx, const rc_opts *opts);
 /* replaces the interop copy of Run (RayTracingKernel.cpp:18-27): waits, then copies the float frame
  * (row 0 = bottom) / its RGBA8 conversion (flip != 0: top row first) to HOST memory */

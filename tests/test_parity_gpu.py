@@ -691,6 +691,17 @@ def test_context_api_end_to_end(oracle, rclib, tmp_path):
     cam2 = oracle.camera_data(pc.position, pc.rotation, w, h)
     want = oracle.render(pos2, rad2, col2, cam2, w, h)
     assert_same_bits(got, want, "context, caller scene after input")
+    # culled variant through the context: it lends its own workspace
+    big = oracle.generate_scene(2500, 9)
+    abi.check(rclib.rc_scene_upload(ctx, 2500, *(a.ctypes.data_as(C.c_void_p) for a in big)), "rc_scene_upload")
+    copts = abi.RcOpts(variant=abi.VARIANT_CULLED)
+    for _ in range(2):
+        abi.check(rclib.rc_ctx_render(ctx, C.byref(copts)), "rc_ctx_render culled")
+    abi.check(rclib.rc_readback(ctx, got.ctypes.data_as(C.c_void_p), w * 16), "rc_readback")
+    assert_same_bits(got, oracle.render(*big, cam2, w, h), "context, culled with its own workspace")
+    abi.check(rclib.rc_scene_upload(ctx, 25, pos2.ctypes.data_as(C.c_void_p), rad2.ctypes.data_as(C.c_void_p),
+                                    col2.ctypes.data_as(C.c_void_p)), "rc_scene_upload")
+    abi.check(rclib.rc_ctx_render(ctx, None), "rc_ctx_render")
     img = np.empty((h, w, 4), np.uint8)
     abi.check(rclib.rc_readback_rgba8(ctx, img.ctypes.data_as(C.c_void_p), w * 4, 1), "rc_readback_rgba8")
     want8 = oracle.to_rgba8(want, flip=True)
