@@ -798,3 +798,15 @@ def test_c_example_renders_the_reference_frame(oracle, tmp_path):
     data = out.read_bytes()
     img = np.frombuffer(data[len(head):], np.uint8).reshape(h, w, 3)
     assert np.array_equal(img, oracle.to_rgba8(want, flip=True)[..., :3])
+
+
+@pytest.mark.parametrize("w,h,n", [(65536, 2, 3), (2, 65536, 3), (64, 32, 70000)])
+def test_extreme_shapes(oracle, w, h, n):
+    """The widest and the tallest frame the library accepts, and more spheres than 16-bit bin lists
+    can index (the culled variant then works from the records alone)."""
+    pos, rad, col = oracle.generate_scene(n, 2)
+    cam = oracle.camera_data((0, 0, 20), (0.01, 0.02, 0), w, h)
+    want = oracle.render(pos, rad, col, cam, w, h)
+    for variant, ws in [(abi.VARIANT_AUTO, False), (abi.VARIANT_CULLED, True), (abi.VARIANT_LITERAL, False)]:
+        got = pixels(gpu_render(pos, rad, col, cam, w, h, variant=variant, workspace=ws), w)
+        assert_same_bits(got, want, f"{w}x{h} n={n} variant {variant}")
