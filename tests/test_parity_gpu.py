@@ -14,6 +14,7 @@ import pytest
 
 from conftest import ROOT
 from cudaraytracing_amd import abi, configs
+from cudaraytracing_amd.host import DeviceBuffer
 from gpu_util import GpuScene, assert_same_bits, gpu_render, pixels
 
 pytestmark = pytest.mark.gpu
@@ -530,9 +531,13 @@ def test_bench_contract_line():
     assert d["config"]["workload"] == "c2_1920x1080_n64"
     for k in ("bound", "achieved", "peak", "unit", "frac", "traffic"):
         assert k in d["roofline"], k
-    for k in ("value", "unit", "cores", "kind", "sample"):
+    # a roofline fraction prices work the kernel executes: it cannot exceed 1
+    assert 0.0 < d["roofline"]["frac"] <= 1.0
+    assert abs(d["roofline"]["frac"] - d["roofline"]["achieved"] / d["roofline"]["peak"]) < 1e-9
+    for k in ("value", "unit", "cores", "kind", "sample", "box_threads"):
         assert k in d["cpu_baseline"], k
     assert d["cpu_baseline"]["kind"] == "port" and d["cpu_baseline"]["cores"] >= 1
+    assert d["cpu_baseline"]["box_threads"] >= d["cpu_baseline"]["cores"] or d["cpu_baseline"]["cores"] == d["cpu_baseline"]["job_cpu_share"]
 
 
 def test_prepare_then_render(oracle, rclib):
@@ -758,15 +763,19 @@ def test_workspace_is_validated(rclib):
         b.free()
 
 
-@pytest.mark.parametrize("mode,extra", [("bands", ["--gather", "rgba8"]), ("bands", []), ("frames", ["--sequence"])])
-def test_bench_two_ranks_share_one_gpu(mode, extra):
+@pytest.mark.parametrize("mode,extra,launcher", [("bands", ["--gather", "rgba8"], True), ("bands", [], False),
+                                                 ("frames", ["--sequence"], True), ("frames", [], False)])
+def test_bench_two_ranks_share_one_gpu(mode, extra, launcher):
     """bench.py's N>1 launch contract with two ranks on this one GPU (gloo instead of RCCL, both ranks
-    on device 0): one JSON line from rank 0; in bands mode the gathered frame equals the whole frame."""
+    on device 0): one JSON line from rank 0; in bands mode the gathered frame equals the whole frame.
+    launcher=False: plain `python bench.py --gpus 2`, which must start its two ranks itself."""
     import json, socket, sys
     s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
-    env = dict(os.environ, RC_BENCH_BACKEND="gloo", RC_BENCH_SHARE_GPU="1")
-    r = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2",
-                        "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.join(ROOT, "bench.py"),
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
+    env.update(RC_BENCH_BACKEND="gloo", RC_BENCH_SHARE_GPU="1")
+    head = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2",
+            "--master-addr", "127.0.0.1", "--master-port", str(port)] if launcher else [sys.executable]
+    r = subprocess.run(head + [os.path.join(ROOT, "bench.py"),
                         "--gpus", "2", "--steps", "6", "--warmup", "2", "--mode", mode, "--config", "c2_1920x1080_n64",
                         "--no-clock-ramp"] + extra, capture_output=True, text=True, timeout=400, env=env)
     assert r.returncode == 0, r.stderr[-3000:]
@@ -777,6 +786,58 @@ def test_bench_two_ranks_share_one_gpu(mode, extra):
     assert d["scaling"] == ("strong" if mode == "bands" else "weak")
     if mode == "bands":
         assert d["gather_check"] is True
+
+
+@pytest.mark.parametrize("extra", [[], ["--gather", "rgba8", "--subbands", "3"]])
+def test_bench_band_assembly_on_device_tensors_one_rank(extra):
+    """--mode bands on ONE rank still renders the band piece by piece (y_offset / full_height) and
+    assembles the pieces on device tensors under a one-rank RCCL process group: the assembled frame
+    must equal the frame rendered whole, bit for bit."""
+    import json, sys
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "1", "--steps", "6", "--warmup", "2",
+                        "--mode", "bands", "--config", "c2_1920x1080_n64", "--no-clock-ramp", "--no-cpu"] + extra,
+                       capture_output=True, text=True, timeout=400, env=env)
+    assert r.returncode == 0, r.stderr[-3000:]
+    lines = [l for l in r.stdout.splitlines() if l.strip()]
+    assert len(lines) == 1, r.stdout
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 1 and d["scaling"] == "strong" and d["gather_check"] is True
+    assert d["config"]["sharding"] == "bands"
+
+
+def test_config4_split_eight_bands_two_pieces_each(oracle, golden):
+    """The 7680x4320 x 4096 frame exactly as eight GPUs would render it -- eight row bands of 540 rows,
+    each in two sub-bands (rc_opts.y_offset / full_height) -- on this one GPU, straight into the rows
+    of one full frame: the assembled frame has the committed hash of the frame rendered whole."""
+    from cudaraytracing_amd import sharding
+    fx = golden["c4_7680x4320_n4096"]
+    w, h = fx["width"], fx["height"]
+    pos, rad, col = oracle.generate_scene(fx["n"], fx["seed"])
+    cam = oracle.camera_data(fx["position"], fx["rotation"], w, h)
+    lib = abi.load()
+    scene = GpuScene(pos, rad, col)
+    sc = scene.scene(cam)
+    pitch = w * 16
+    surf = DeviceBuffer(pitch * h)
+    abi.check(lib.rc_memset(surf.ptr, 1, pitch * h, None))
+    pieces = 0
+    for r in range(8):
+        b, e = configs.band_rows(h, 8, r)
+        assert e - b == 540
+        for sb, se in sharding.sub_bands(b, e, 2):
+            screen = abi.RcScreen(surf.ptr.value + sb * pitch, w, se - sb, pitch)
+            opts = abi.RcOpts(y_offset=sb, full_height=h)
+            abi.check(lib.rc_render(C.byref(screen), C.byref(sc), C.byref(opts)), "rc_render")
+            pieces += 1
+    assert pieces == 16
+    abi.check(lib.rc_sync(None))
+    got = np.empty((h, w, 4), np.float32)
+    abi.check(lib.rc_download_2d(got.ctypes.data_as(C.c_void_p), pitch, surf.ptr, pitch, pitch, h, None))
+    surf.free()
+    scene.free()
+    assert f"{oracle.fnv_words(got):016x}" == fx["fnv"]
+    assert int(got[..., :3].any(axis=2).sum()) == fx["lit_pixels"]
 
 
 def test_c_example_renders_the_reference_frame(oracle, tmp_path):

@@ -107,3 +107,32 @@ def test_frames_round_robin():
         assert seen == list(range(300))
         sizes = [len(sharding.frames_for_rank(300, world, r)) for r in range(world)]
         assert max(sizes) - min(sizes) <= 1
+
+
+@pytest.mark.parametrize("gpus", [2, 3])
+def test_bench_starts_its_own_ranks_without_a_launcher(gpus):
+    """`python bench.py --gpus N` outside torch.distributed.run starts the N ranks itself (a child
+    launcher, 127.0.0.1 rendezvous) and relays rank 0's one line.  RC_BENCH_DRY_RUN=1: the ranks
+    rendezvous over gloo, run the barrier and the MAX reduction, and render nothing (no GPU here)."""
+    import json
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
+    env["RC_BENCH_DRY_RUN"] = "1"
+    r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", str(gpus), "--steps", "6", "--warmup", "1"],
+                       capture_output=True, text=True, timeout=300, env=env)
+    assert r.returncode == 0, r.stderr[-3000:]
+    lines = [ln for ln in r.stdout.splitlines() if ln.strip()]
+    assert len(lines) == 1, r.stdout
+    d = json.loads(lines[0])
+    assert d["dry_run"] is True and d["n_gpus"] == gpus and d["steps"] == 6 and d["max_rank"] == gpus - 1
+
+
+def test_bench_refuses_a_world_size_that_contradicts_gpus():
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, WORLD_SIZE="3", RANK="0", RC_BENCH_DRY_RUN="1")
+    r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2"], capture_output=True, text=True, timeout=120, env=env)
+    assert r.returncode != 0 and "WORLD_SIZE" in r.stderr
