@@ -35,7 +35,6 @@ public:
         cam = Camera(screen_width, screen_height);
         cam.position = rc_vec3{0.0f, 0.0f, 20.0f};
         UpdateCamera();
-        scene.sphere_num = sphere_num;
         h_position.resize(sphere_num);
         h_radius.resize(sphere_num);
         h_color.resize(sphere_num);
@@ -49,9 +48,7 @@ public:
     {
         if (position.size() != radius.size() || color.size() != radius.size())
             throw std::invalid_argument("SetScene: array sizes differ");
-        FreeArrays();
         h_position = position; h_radius = radius; h_color = color;
-        scene.sphere_num = (int)radius.size();
         Upload();
     }
 
@@ -66,15 +63,33 @@ public:
     ~SceneManager() { FreeArrays(); }
 
 private:
-    void Upload()                                         // SceneManager.cpp:17-24
+    // SceneManager.cpp:17-24.  The host arrays go to fresh device arrays first; the scene switches to
+    // them only once all three are allocated and filled.  A failure part-way frees what it made and
+    // leaves an EMPTY scene (sphere_num 0, no arrays), never a half-built one.
+    void Upload()
     {
-        const size_t n = (size_t)scene.sphere_num;
-        check(rc_malloc((void **)&scene.position, sizeof(rc_vec3) * n), "rc_malloc(position)");
-        check(rc_malloc((void **)&scene.radius, sizeof(float) * n), "rc_malloc(radius)");
-        check(rc_malloc((void **)&scene.color, sizeof(rc_vec3) * n), "rc_malloc(color)");
-        check(rc_upload(scene.position, h_position.data(), sizeof(rc_vec3) * n, nullptr), "rc_upload(position)");
-        check(rc_upload(scene.radius, h_radius.data(), sizeof(float) * n, nullptr), "rc_upload(radius)");
-        check(rc_upload(scene.color, h_color.data(), sizeof(rc_vec3) * n, nullptr), "rc_upload(color)");
+        const size_t n = h_radius.size();
+        void *d[3] = {nullptr, nullptr, nullptr};
+        const void *src[3] = {h_position.data(), h_radius.data(), h_color.data()};
+        const size_t bytes[3] = {sizeof(rc_vec3) * n, sizeof(float) * n, sizeof(rc_vec3) * n};
+        static const char *const what[3] = {"position", "radius", "color"};
+        FreeArrays();
+        scene.sphere_num = 0;
+        for (int i = 0; i < 3; i++) {
+            int rc = rc_malloc(&d[i], bytes[i]);
+            if (rc == RC_OK) rc = rc_upload(d[i], src[i], bytes[i], nullptr);
+            if (rc != RC_OK) {
+                const std::string msg = std::string("scene upload (") + what[i] + "): " + rc_last_error_string();
+                for (int k = 0; k <= i; k++)
+                    if (d[k]) rc_free(d[k]);
+                h_position.clear(); h_radius.clear(); h_color.clear();
+                throw Error(rc, msg);
+            }
+        }
+        scene.position = static_cast<rc_vec3 *>(d[0]);
+        scene.radius = static_cast<float *>(d[1]);
+        scene.color = static_cast<rc_vec3 *>(d[2]);
+        scene.sphere_num = (int)n;
     }
     void FreeArrays()
     {

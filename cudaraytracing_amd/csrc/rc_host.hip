@@ -68,6 +68,7 @@ struct SinTables {
     int width, full_height;
     float *d_base;   // [width + full_height]
     uint64_t last_use;
+    int pinned;      // looked up while a stream was being captured: a graph node holds d_base, never evicted
 };
 
 std::shared_mutex g_mu;
@@ -76,11 +77,12 @@ uint64_t g_tick = 0;
 constexpr size_t kMaxTables = 32;   // per device
 
 // caller holds g_mu (shared or exclusive)
-bool rc_find_tables(int dev, uint32_t fb, int width, int full_height, const float **sx, const float **sy)
+bool rc_find_tables(int dev, uint32_t fb, int width, int full_height, const float **sx, const float **sy, bool pin = false)
 {
     for (auto &t : g_tables) {
         if (t.device == dev && t.fov_bits == fb && t.width == width && t.full_height == full_height) {
             __atomic_store_n(&t.last_use, __atomic_add_fetch(&g_tick, 1, __ATOMIC_RELAXED), __ATOMIC_RELAXED);
+            if (pin) __atomic_store_n(&t.pinned, 1, __ATOMIC_RELAXED);
             *sx = t.d_base;
             *sy = t.d_base + width;
             return true;
@@ -97,11 +99,17 @@ int rc_build_tables(int dev, uint32_t fb, float fov, int width, int full_height)
     size_t mine = 0;
     for (const auto &t : g_tables) mine += (t.device == dev);
     if (mine >= kMaxTables) {
-        // evict this device's least recently used entry once the frames that read it have finished
+        // evict this device's least recently used entry once the frames that read it have finished;
+        // tables a captured graph may replay at any later time are never evicted
         size_t victim = g_tables.size();
         for (size_t i = 0; i < g_tables.size(); i++)
-            if (g_tables[i].device == dev && (victim == g_tables.size() || g_tables[i].last_use < g_tables[victim].last_use))
+            if (g_tables[i].device == dev && !g_tables[i].pinned &&
+                (victim == g_tables.size() || g_tables[i].last_use < g_tables[victim].last_use))
                 victim = i;
+        if (victim == g_tables.size()) {
+            snprintf(g_err, sizeof(g_err), "all %zu cached frame formats of this device are held by captured graphs", kMaxTables);
+            return RC_EINVAL;
+        }
         RC_HIP(hipDeviceSynchronize());
         RC_HIP(hipFree(g_tables[victim].d_base));
         g_tables.erase(g_tables.begin() + (long)victim);
@@ -111,7 +119,7 @@ int rc_build_tables(int dev, uint32_t fb, float fov, int width, int full_height)
         h[(size_t)x] = sinf(fov * (1.0f * (float)x / (float)width - 0.5f));
     for (int y = 0; y < full_height; y++)
         h[(size_t)width + (size_t)y] = sinf(fov * (1.0f * (float)y / (float)full_height - 0.5f));
-    SinTables t{dev, fb, width, full_height, nullptr, ++g_tick};
+    SinTables t{dev, fb, width, full_height, nullptr, ++g_tick, 0};
     RC_HIP(hipMalloc(reinterpret_cast<void **>(&t.d_base), h.size() * sizeof(float)));
     hipError_t e = hipMemcpy(t.d_base, h.data(), h.size() * sizeof(float), hipMemcpyHostToDevice);
     if (e != hipSuccess) {
@@ -131,15 +139,19 @@ int rc_get_tables(float fov, int width, int full_height, const float **sx, const
     RC_HIP(hipGetDevice(&dev));
     uint32_t fb;
     memcpy(&fb, &fov, 4);
+    // A kernel node recorded into a graph keeps the table's address for as long as the graph lives,
+    // so a table looked up during a capture is pinned (exempt from eviction) from then on.
+    bool capturing = false;
+    if (stream) {
+        hipStreamCaptureStatus st = hipStreamCaptureStatusNone;
+        capturing = hipStreamIsCapturing(stream, &st) == hipSuccess && st == hipStreamCaptureStatusActive;
+    }
     for (int attempt = 0; attempt < 8; attempt++) {
         lease = std::shared_lock<std::shared_mutex>(g_mu);
-        if (rc_find_tables(dev, fb, width, full_height, sx, sy)) return RC_OK;
+        if (rc_find_tables(dev, fb, width, full_height, sx, sy, capturing)) return RC_OK;
         lease.unlock();
-        if (stream) {       // building allocates and copies: not possible while the stream is being captured
-            hipStreamCaptureStatus st = hipStreamCaptureStatusNone;
-            if (hipStreamIsCapturing(stream, &st) == hipSuccess && st == hipStreamCaptureStatusActive)
-                return rc_fail_arg("frame format not prepared: call rc_prepare(width, full_height, fov) before capturing");
-        }
+        if (capturing)      // building allocates and copies: not possible while the stream is being captured
+            return rc_fail_arg("frame format not prepared: call rc_prepare(width, full_height, fov) before capturing");
         std::unique_lock<std::shared_mutex> build(g_mu);
         int rc = rc_build_tables(dev, fb, fov, width, full_height);
         if (rc != RC_OK) return rc;
@@ -169,7 +181,11 @@ int rc_compute_units(int dev, int *cus)
 
 // ---- hot path ------------------------------------------------------------------------------
 
-extern "C" int rc_render(const rc_screen *screen, const rc_scene *scene, const rc_opts *opts)
+namespace {
+
+// Argument checks of rc_render; fills the effective options.
+int rc_check_render_args(const rc_screen *screen, const rc_scene *scene, const rc_opts *opts, rc_opts &o,
+                         int &full_height, int &kv)
 {
     if (!screen || !scene) return rc_fail_arg("null screen or scene");
     if (!screen->surface) return rc_fail_arg("null surface");
@@ -183,10 +199,9 @@ extern "C" int rc_render(const rc_screen *screen, const rc_scene *scene, const r
     if (scene->sphere_num > 0 && (!scene->position || !scene->radius || !scene->color))
         return rc_fail_arg("null scene array");
 
-    rc_opts o;
     memset(&o, 0, sizeof(o));
     if (opts) o = *opts;
-    int full_height = o.full_height > 0 ? o.full_height : screen->height;
+    full_height = o.full_height > 0 ? o.full_height : screen->height;
     if (o.y_offset < 0 || (long long)o.y_offset + screen->height > full_height)
         return rc_fail_arg("row band [y_offset, y_offset+height) exceeds full_height");
     if (o.rgba8 && (o.rgba8_pitch < (size_t)screen->width * 4 || (o.rgba8_pitch & 3) != 0 ||
@@ -199,7 +214,6 @@ extern "C" int rc_render(const rc_screen *screen, const rc_scene *scene, const r
         if (o.ext->shininess_log2 < 0 || o.ext->shininess_log2 > 30) return rc_fail_arg("shininess_log2 must be 0..30");
     }
 
-    int kv;
     switch (o.variant) {
     case RC_VARIANT_AUTO:
     case RC_VARIANT_TILED: kv = RC_KVARIANT_AUTO; break;
@@ -210,12 +224,14 @@ extern "C" int rc_render(const rc_screen *screen, const rc_scene *scene, const r
     case RC_VARIANT_CULLED: kv = RC_KVARIANT_AUTO; break;
     default: return rc_fail_arg("unknown variant");
     }
+    return RC_OK;
+}
 
-    const float *sx = nullptr, *sy = nullptr;
-    std::shared_lock<std::shared_mutex> lease;     // held until the kernel is enqueued
-    int rc = rc_get_tables(scene->cam.fov, screen->width, full_height, &sx, &sy, lease, static_cast<hipStream_t>(o.stream));
-    if (rc != RC_OK) return rc;
-
+// Fills the kernel argument block and enqueues the frame.  sx / sy: device sine tables of this
+// frame format; workspace (device, may be null): scratch of the culled variant.
+int rc_enqueue_frame(const rc_screen *screen, const rc_scene *scene, const rc_opts &o, int kv,
+                     const float *sx, const float *sy, void *workspace, size_t workspace_bytes)
+{
     RcKernArgs a;
     memset(&a, 0, sizeof(a));
     a.surface = screen->surface;
@@ -267,25 +283,40 @@ extern "C" int rc_render(const rc_screen *screen, const rc_scene *scene, const r
 
     int dev = 0, cus = 0;
     RC_HIP(hipGetDevice(&dev));
-    rc = rc_compute_units(dev, &cus);
+    int rc = rc_compute_units(dev, &cus);
     if (rc != RC_OK) return rc;
-    if (a.cull && o.workspace && a.n > 0) {
-        if ((reinterpret_cast<uintptr_t>(o.workspace) & 15) != 0 || o.workspace_bytes < rc_workspace_bytes(a.n))
+    if (a.cull && workspace && a.n > 0) {
+        if ((reinterpret_cast<uintptr_t>(workspace) & 15) != 0 || workspace_bytes < rc_workspace_bytes(a.n))
             return rc_fail_arg("workspace must be 16-byte aligned and hold rc_workspace_bytes(sphere_num) bytes");
-        float4 *records = static_cast<float4 *>(o.workspace);
+        float4 *records = static_cast<float4 *>(workspace);
         hipError_t er = rc_launch_records(a, records, static_cast<hipStream_t>(o.stream));
         if (er != hipSuccess) return rc_fail_hip(er, "record kernel launch");
         a.records = records;
         // level 0 (per-bin sphere lists) when the workspace also has room for it
         const size_t rec_bytes = (rc_workspace_bytes(a.n) + 255) & ~(size_t)255;
-        if (o.workspace_bytes > rec_bytes && a.n >= kMinBinnedSpheres) {
-            a.bins = static_cast<const unsigned char *>(o.workspace) + rec_bytes;
-            a.bins_bytes = o.workspace_bytes - rec_bytes;
+        if (workspace_bytes > rec_bytes && a.n >= kMinBinnedSpheres) {
+            a.bins = static_cast<const unsigned char *>(workspace) + rec_bytes;
+            a.bins_bytes = workspace_bytes - rec_bytes;
         }
     }
     hipError_t e = rc_launch_draw(a, kv, cus, static_cast<hipStream_t>(o.stream));
     if (e != hipSuccess) return rc_fail_hip(e, "draw kernel launch");
     return RC_OK;
+}
+
+} // namespace
+
+extern "C" int rc_render(const rc_screen *screen, const rc_scene *scene, const rc_opts *opts)
+{
+    rc_opts o;
+    int full_height = 0, kv = 0;
+    int rc = rc_check_render_args(screen, scene, opts, o, full_height, kv);
+    if (rc != RC_OK) return rc;
+    const float *sx = nullptr, *sy = nullptr;
+    std::shared_lock<std::shared_mutex> lease;     // held until the kernel is enqueued
+    rc = rc_get_tables(scene->cam.fov, screen->width, full_height, &sx, &sy, lease, static_cast<hipStream_t>(o.stream));
+    if (rc != RC_OK) return rc;
+    return rc_enqueue_frame(screen, scene, o, kv, sx, sy, o.workspace, o.workspace_bytes);
 }
 
 extern "C" size_t rc_workspace_bytes(int sphere_num)
@@ -693,8 +724,17 @@ template <class F>
 int rc_ctx_call(rc_ctx *ctx, F body)
 {
     if (!ctx) return rc_fail_arg("null context");
+    // the caller's current device is put back on every way out (a multi-GPU caller's own raw
+    // rc_malloc / rc_render calls must not be silently retargeted by a context call)
+    struct Restore {
+        int prev = -1;
+        ~Restore() { if (prev >= 0) (void)hipSetDevice(prev); }
+    } restore;
+    int prev = -1;
+    RC_HIP(hipGetDevice(&prev));
+    RC_HIP(hipSetDevice(ctx->device));
+    if (prev != ctx->device) restore.prev = prev;
     try {
-        RC_HIP(hipSetDevice(ctx->device));
         body(ctx->rtk);
         return RC_OK;
     } catch (const rc::Error &e) {

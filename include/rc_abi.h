@@ -196,7 +196,9 @@ int rc_download_2d_async(void *dst_host, size_t dst_pitch, const void *src_devic
  * rc_to_rgba8, rc_download_2d_async -- is recorded instead of executed; rc_graph_launch replays the
  * whole sequence with one submission.  `stream` must be a stream from rc_stream_create (the default
  * stream cannot be captured), and rc_prepare (or one earlier rc_render) must have built the sine
- * tables of every frame format used inside the capture, because a capture cannot allocate.  No
+ * tables of every frame format used inside the capture, because a capture cannot allocate.  A graph
+ * node keeps the address of its format's tables, so a format used inside a capture stays in the table
+ * cache (at most 32 formats per device) for the rest of the process, also after rc_graph_destroy.  No
  * counterpart in the reference, which launches frame by frame (RayTracingKernel.cpp:17). */
 int rc_graph_begin(void *stream);
 int rc_graph_end(void *stream, void **graph_exec);
@@ -246,6 +248,9 @@ int rc_write_ppm(const char *path, const uint8_t *rgba8, size_t pitch, int width
  * surface, as RayTracingKernel owns `screen` and `sm` (RayTracingKernel.h).  A convenience layer over
  * the calls above for C and FFI callers; the C++ classes in csrc/host/ are the same layer in C++. */
 typedef struct rc_ctx rc_ctx;
+/* Every rc_ctx_* call runs with the context's device current and puts the caller's current device
+ * back before it returns.  A failed rc_scene_generate / rc_scene_upload leaves the context with an
+ * empty scene (0 spheres), never a partly uploaded one. */
 /* RayTracingKernel::Init (RayTracingKernel.cpp:34-45) without the scene: picks `device`, records the
  * frame size, camera at (0,0,20) looking down -z (SceneManager.cpp:4-6). */
 int rc_ctx_create(rc_ctx **ctx, int device, int width, int height);

@@ -655,6 +655,44 @@ def test_graph_capture_and_replay(oracle, rclib):
     abi.check(rclib.rc_stream_destroy(stream))
 
 
+def test_graph_tables_survive_cache_eviction(oracle, rclib):
+    """A captured graph keeps the address of its frame format's sine tables.  Rendering more other
+    formats than the table cache holds (32) afterwards must not evict (free) those tables: the
+    replay still produces the oracle's frame."""
+    w, h, n = 168, 96, 30
+    pos, rad, col = oracle.generate_scene(n, 9)
+    gs = GpuScene(pos, rad, col)
+    cam = oracle.camera_data((0, 0, 20), (0.02, 0.04, 0), w, h)
+    stream = C.c_void_p()
+    abi.check(rclib.rc_stream_create(C.byref(stream)))
+    abi.check(rclib.rc_prepare(w, h, cam.fov))
+    surf = DeviceBuffer(w * 16 * h)
+    screen = abi.RcScreen(surf.ptr.value, w, h, w * 16)
+    opts = abi.RcOpts(stream=stream)
+    sc = gs.scene(cam)
+    abi.check(rclib.rc_graph_begin(stream), "rc_graph_begin")
+    abi.check(rclib.rc_render(C.byref(screen), C.byref(sc), C.byref(opts)), "rc_render in capture")
+    exe = C.c_void_p()
+    abi.check(rclib.rc_graph_end(stream, C.byref(exe)), "rc_graph_end")
+    # 40 other formats through the cache; each one allocates (and, from the 33rd on, evicts)
+    for i in range(40):
+        ow, oh = 48 + 2 * i, 20 + i
+        ocam = oracle.camera_data((0, 0, 20), (0, 0, 0), ow, oh)
+        got = pixels(gpu_render(None, None, None, ocam, ow, oh, scene=gs), ow)
+        if i in (0, 39):
+            assert_same_bits(got, oracle.render(pos, rad, col, ocam, ow, oh), f"format {ow}x{oh}")
+    abi.check(rclib.rc_memset(surf.ptr, 0x33, w * 16 * h, stream))
+    abi.check(rclib.rc_graph_launch(exe, stream), "rc_graph_launch")
+    abi.check(rclib.rc_sync(stream))
+    got = np.empty((h, w, 4), np.float32)
+    abi.check(rclib.rc_download_2d(got.ctypes.data_as(C.c_void_p), w * 16, surf.ptr, w * 16, w * 16, h, stream))
+    assert_same_bits(got, oracle.render(pos, rad, col, cam, w, h), "graph replay after 40 other formats")
+    abi.check(rclib.rc_graph_destroy(exe))
+    surf.free()
+    gs.free()
+    abi.check(rclib.rc_stream_destroy(stream))
+
+
 def test_context_api_end_to_end(oracle, rclib, tmp_path):
     """rc_ctx_*: the reference's RayTracingKernel + SceneManager life cycle through plain C calls --
     create, random scene, surface, render, read back; then a caller scene, a camera move, one
