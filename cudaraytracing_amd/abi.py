@@ -72,6 +72,7 @@ assert C.sizeof(RcOpts) == 72 and RcOpts.workspace.offset == 56 and C.sizeof(RcI
 # every symbol include/rc_abi.h declares: name -> (restype, argtypes)
 SYMBOLS = {
     "rc_render": (C.c_int, [C.POINTER(RcScreen), C.POINTER(RcScene), C.POINTER(RcOpts)]),
+    "rc_render_static": (C.c_int, [C.POINTER(RcScreen), C.POINTER(RcScene), C.POINTER(RcOpts)]),
     "rc_workspace_bytes": (C.c_size_t, [C.c_int]),
     "rc_workspace_bytes_frame": (C.c_size_t, [C.c_int, C.c_int, C.c_int]),
     "rc_prepare": (C.c_int, [C.c_int, C.c_int, C.c_float]),

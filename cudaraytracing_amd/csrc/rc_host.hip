@@ -183,7 +183,7 @@ int rc_compute_units(int dev, int *cus)
 
 namespace {
 
-// Argument checks of rc_render; fills the effective options.
+// Argument checks shared by rc_render and rc_render_static; fills the effective options.
 int rc_check_render_args(const rc_screen *screen, const rc_scene *scene, const rc_opts *opts, rc_opts &o,
                          int &full_height, int &kv)
 {
@@ -317,6 +317,90 @@ extern "C" int rc_render(const rc_screen *screen, const rc_scene *scene, const r
     rc = rc_get_tables(scene->cam.fov, screen->width, full_height, &sx, &sy, lease, static_cast<hipStream_t>(o.stream));
     if (rc != RC_OK) return rc;
     return rc_enqueue_frame(screen, scene, o, kv, sx, sy, o.workspace, o.workspace_bytes);
+}
+
+// ---- rc_render_static: the same frame with no device allocation at all ----------------------
+// The library's device scratch -- the sine tables rc_render keeps in hipMalloc'ed cache entries and,
+// for RC_VARIANT_CULLED, the per-frame sphere records a caller workspace would hold -- lives in one
+// file-scope device array.  Every GPU has its own copy of the array at its own address
+// (hipGetSymbolAddress, once per device, with that device current); host code only ever uses that
+// address, never the array's name.
+constexpr int kStaticTableFloats = 32768;                 // width + full_height of the frame format
+constexpr int kStaticRecords = 8192;                      // spheres, RC_VARIANT_CULLED only
+constexpr size_t kStaticTableBytes = (size_t)kStaticTableFloats * sizeof(float);
+constexpr size_t kStaticScratchBytes = kStaticTableBytes + (size_t)kStaticRecords * 16;
+constexpr int kStaticDevices = 16;
+
+static __device__ __align__(256) unsigned char rc_static_scratch[kStaticScratchBytes];
+
+namespace {
+struct StaticScratch {
+    std::mutex mu;
+    unsigned char *ptr = nullptr;      // this device's copy of rc_static_scratch
+    bool loaded = false;               // tables of (fov_bits, width, full_height) are in ptr[0, 4 (width + full_height))
+    uint32_t fov_bits = 0;
+    int width = 0, full_height = 0;
+};
+StaticScratch g_static[kStaticDevices];
+float g_static_stage[kStaticDevices][kStaticTableFloats];   // host side of the table upload, one per device
+} // namespace
+
+extern "C" int rc_render_static(const rc_screen *screen, const rc_scene *scene, const rc_opts *opts)
+{
+    rc_opts o;
+    int full_height = 0, kv = 0;
+    int rc = rc_check_render_args(screen, scene, opts, o, full_height, kv);
+    if (rc != RC_OK) return rc;
+    if ((long long)screen->width + full_height > kStaticTableFloats) {
+        snprintf(g_err, sizeof(g_err), "rc_render_static: width + full_height = %lld exceeds the static table of %d entries (use rc_render)",
+                 (long long)screen->width + full_height, kStaticTableFloats);
+        return RC_EINVAL;
+    }
+    if (o.variant == RC_VARIANT_CULLED && scene->sphere_num > kStaticRecords) {
+        snprintf(g_err, sizeof(g_err), "rc_render_static: RC_VARIANT_CULLED with %d spheres exceeds the static record area of %d (use rc_render with a workspace)",
+                 scene->sphere_num, kStaticRecords);
+        return RC_EINVAL;
+    }
+    int dev = 0;
+    RC_HIP(hipGetDevice(&dev));
+    if (dev < 0 || dev >= kStaticDevices) return rc_fail_arg("rc_render_static: device index above 15");
+    StaticScratch &st = g_static[dev];
+    std::lock_guard<std::mutex> lock(st.mu);
+    if (!st.ptr) {
+        void *p = nullptr;
+        RC_HIP(hipGetSymbolAddress(&p, HIP_SYMBOL(rc_static_scratch)));
+        st.ptr = static_cast<unsigned char *>(p);
+    }
+    hipStream_t stream = static_cast<hipStream_t>(o.stream);
+    uint32_t fb;
+    memcpy(&fb, &scene->cam.fov, 4);
+    if (!st.loaded || st.fov_bits != fb || st.width != screen->width || st.full_height != full_height) {
+        // New frame format: tabulate on the host (kernel.cu:46-47, libm sinf) and upload on the caller's
+        // stream, behind the frames already enqueued there that read the previous tables.  The wait makes
+        // the staging array free for the next format change, whichever stream that comes from.
+        hipStreamCaptureStatus cs = hipStreamCaptureStatusNone;
+        if (stream && hipStreamIsCapturing(stream, &cs) == hipSuccess && cs == hipStreamCaptureStatusActive)
+            return rc_fail_arg("rc_render_static: this frame format is not loaded; render one frame of it before capturing");
+        const float fov = scene->cam.fov;
+        const int width = screen->width;
+        float *h = g_static_stage[dev];
+        for (int x = 0; x < width; x++)
+            h[x] = sinf(fov * (1.0f * (float)x / (float)width - 0.5f));
+        for (int y = 0; y < full_height; y++)
+            h[width + y] = sinf(fov * (1.0f * (float)y / (float)full_height - 0.5f));
+        st.loaded = false;
+        RC_HIP(hipMemcpyAsync(st.ptr, h, ((size_t)width + (size_t)full_height) * sizeof(float), hipMemcpyHostToDevice, stream));
+        RC_HIP(hipStreamSynchronize(stream));
+        st.loaded = true;
+        st.fov_bits = fb;
+        st.width = width;
+        st.full_height = full_height;
+    }
+    const float *sx = reinterpret_cast<const float *>(st.ptr);
+    void *records = (o.variant == RC_VARIANT_CULLED) ? st.ptr + kStaticTableBytes : nullptr;
+    // exactly the records' size: the per-bin lists of the culled variant are not kept in the static array
+    return rc_enqueue_frame(screen, scene, o, kv, sx, sx + screen->width, records,
+                            records ? rc_workspace_bytes(scene->sphere_num) : 0);
 }
 
 extern "C" size_t rc_workspace_bytes(int sphere_num)

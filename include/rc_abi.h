@@ -146,6 +146,23 @@ int rc_render(const rc_screen *screen, const rc_scene *scene, const rc_opts *opt
  * No counterpart in the reference, which evaluates sinf per pixel on the device. */
 int rc_prepare(int width, int full_height, float fov);
 
+/* rc_render for callers that cannot allocate device memory: code under HIP graph capture, tight
+ * serving loops, harnesses that forbid hipMalloc.  It has NO counterpart in the reference.  Same
+ * arguments, same frames as rc_render, but the device scratch the library needs -- the sine tables
+ * and, for RC_VARIANT_CULLED, the per-frame sphere records -- lives in a fixed array inside the
+ * library's code object (256 KiB, held by every GPU the library runs on until the process ends), so
+ * the call never allocates or frees anything on the device or through an allocating library routine.
+ * Limits (RC_EINVAL beyond them): width + full_height <= 32768; RC_VARIANT_CULLED: sphere_num <= 8192;
+ * device index <= 15.  opts->workspace is ignored.
+ * All calls on one GPU share that GPU's array, which keeps the last call's contents; nothing in it has
+ * to start at zero (tables and records are rewritten in full before they are read).  When the frame
+ * format (width, full_height, fov) differs from the previous call's on that GPU, the new tables are
+ * uploaded on opts->stream and the call waits for that stream once (so such a call cannot be captured
+ * into a graph: render one frame of the format first).  Calls that overlap on one GPU -- different
+ * streams or threads without ordering between them -- race on the array unless they use the same
+ * frame format and none uses RC_VARIANT_CULLED. */
+int rc_render_static(const rc_screen *screen, const rc_scene *scene, const rc_opts *opts);
+
 /* Display step after the path (DXManager.cpp:134,299,328: the float texture drawn 1:1 into
  * an R8G8B8A8_UNORM target): NaN->0, clamp [0,1], *255 + 0.5, truncate.  Device to device. */
 int rc_to_rgba8(const rc_screen *screen, void *rgba8, size_t rgba8_pitch, int flip, void *stream);
