@@ -63,6 +63,6 @@ def pytest_sessionstart(session):
     # the checker and, where the reference's sources are present, the cross-checks against its headers
     ref_dir = os.path.join(ROOT, "oracle", "_ref")
     if os.path.isdir("/root/reference/RayCasting/RayCasting") and os.path.exists(abi.LIB_PATH) and \
-            not all(os.path.exists(os.path.join(ref_dir, n)) for n in ("ref_algebra", "ref_input", "dropin_caller")):
+            not all(os.path.exists(os.path.join(ref_dir, n)) for n in ("ref_algebra", "ref_pixel", "ref_input", "dropin_caller")):
         import subprocess
         subprocess.run(["make", "-C", os.path.join(ROOT, "oracle"), "all"], stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL)
