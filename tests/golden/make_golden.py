@@ -6,7 +6,10 @@ surface, of the winner-index map and of the RGBA8 conversion; the hit count; Cam
 and 192 sampled pixels with raw float bits.  Full-size frames take minutes on 8 cores, which is
 why GPU tests compare against these hashes instead of re-running the oracle.
 
-    python tests/golden/make_golden.py [--full]      (--full adds the 4K and 8K frames)
+    python tests/golden/make_golden.py [--full] [--ext-full]
+        --full      adds the 4K and 8K REF frames and the REF frames of the camera path
+        --ext-full  adds EXT at 3840x2160 x 1024 and two EXT frames of the sequence (moving camera AND
+                    orbiting light, configs.sequence_light); EXT fixtures record their rc_ext parameters
 """
 import json
 import os
@@ -57,6 +60,11 @@ def frame_fixture(name, width, height, n, seed, position, rotation, samples=192,
     fx = dict(name=name, width=width, height=height, n=n, seed=seed,
               position=list(position), rotation=list(rotation), mode="EXT" if ext is not None else "REF",
               camera_bits=cam_bits(cam),
+              ext=(None if ext is None else dict(
+                  plane_normal=[ext.plane_normal.x, ext.plane_normal.y, ext.plane_normal.z], plane_h=ext.plane_h,
+                  plane_color=[ext.plane_color.x, ext.plane_color.y, ext.plane_color.z],
+                  light_pos=[ext.light_pos.x, ext.light_pos.y, ext.light_pos.z], specular=ext.specular,
+                  shininess_log2=ext.shininess_log2, has_plane=ext.has_plane, shadows=ext.shadows)),
               fnv=f"{ob.fnv_words(surf):016x}",
               rgba8_flip_fnv=f"{fnv_words_np(rgba8):016x}",
               lit_pixels=int(surf[..., :3].any(axis=2).sum()),
@@ -87,7 +95,23 @@ def main():
         frames.append(frame_fixture(name + "_ext", c["width"], c["height"], c["n"], c["seed"], c["position"],
                                     c["rotation"], ext=ob.Ext(**{k: (ob.Vec3(*v) if isinstance(v, tuple) else v)
                                                                  for k, v in configs.DEFAULT_EXT.items()})))
+    def make_ext(**over):
+        kw = dict(configs.DEFAULT_EXT, **over)
+        return ob.Ext(**{k: (ob.Vec3(*v) if isinstance(v, tuple) else v) for k, v in kw.items()})
+
+    ext_full = "--ext-full" in sys.argv
     s = configs.SEQUENCE
+    ext_big = [("c3_3840x2160_n1024_ext", configs.CONFIGS["c3_3840x2160_n1024"]["position"],
+                configs.CONFIGS["c3_3840x2160_n1024"]["rotation"], make_ext())]
+    for f in (37, 200):
+        p, r = configs.sequence_camera(f)
+        ext_big.append((f"c5_seq_ext_f{f}", p, r, make_ext(light_pos=configs.sequence_light(f))))
+    for name, p, r, e in ext_big:
+        if not ext_full:
+            if name in old:
+                frames.append(old[name])
+            continue
+        frames.append(frame_fixture(name, s["width"], s["height"], s["n"], s["seed"], p, r, ext=e))
     for f in (0, 150, 299, 37):
         name = f"c5_seq_f{f}"
         if not full:

@@ -110,8 +110,9 @@ def test_golden_samples_all_frames(oracle, golden):
                                            C.c_int, C.c_int, C.c_int, C.c_int]
         ext = None
         if fx.get("mode") == "EXT":
-            from cudaraytracing_amd import configs
-            ext = oracle.Ext(**{k: (oracle.Vec3(*v) if isinstance(v, tuple) else v) for k, v in configs.DEFAULT_EXT.items()})
+            e = fx["ext"]                       # the rc_ext parameters the frame was rendered with
+            ext = oracle.Ext(oracle.Vec3(*e["plane_normal"]), e["plane_h"], oracle.Vec3(*e["plane_color"]),
+                             oracle.Vec3(*e["light_pos"]), e["specular"], e["shininess_log2"], e["has_plane"], e["shadows"])
         for s in fx["samples"]:
             x, y = s[0], s[1]
             scr = oracle.Screen(row.ctypes.data, w, 1, w * 16)

@@ -411,6 +411,40 @@ def test_full_size_golden_hashes(oracle, golden, name):
     scene.free()
 
 
+@pytest.mark.parametrize("name", ["c3_3840x2160_n1024_ext", "c5_seq_ext_f37", "c5_seq_ext_f200"])
+def test_full_size_ext_golden_hashes(oracle, golden, name):
+    """EXT (plane, point light, Phong, hard shadows) at 3840x2160 x 1024 spheres, and two frames of the
+    animated sequence (moving camera AND orbiting light), against the oracle's committed hashes.
+    EXT is defined by the oracle; the reference has no such code (unpinned by the reference)."""
+    if name not in golden:
+        pytest.fail(f"{name} missing from tests/golden/golden.json (run make_golden.py --ext-full)")
+    fx = golden[name]
+    w, h = fx["width"], fx["height"]
+    pos, rad, col = oracle.generate_scene(fx["n"], fx["seed"])
+    cam = oracle.camera_data(fx["position"], fx["rotation"], w, h)
+    assert np.frombuffer(C.string_at(C.addressof(cam), C.sizeof(cam)), np.uint32).tolist() == fx["camera_bits"]
+    e = fx["ext"]
+    ext = oracle.Ext(oracle.Vec3(*e["plane_normal"]), e["plane_h"], oracle.Vec3(*e["plane_color"]), oracle.Vec3(*e["light_pos"]),
+                     e["specular"], e["shininess_log2"], e["has_plane"], e["shadows"])
+    scene = GpuScene(pos, rad, col)
+    raw, rgba8 = gpu_render(pos, rad, col, cam, w, h, variant=abi.VARIANT_TILED, want_rgba8=True, flip=True, scene=scene, ext=ext)
+    got = pixels(raw, w)
+    assert f"{oracle.fnv_words(got):016x}" == fx["fnv"]
+    assert int(got[..., :3].any(axis=2).sum()) == fx["lit_pixels"]
+    bits = got.view(np.uint32)
+    for s in fx["samples"]:
+        assert bits[s[1], s[0]].tolist() == s[2:6]
+    flat = np.ascontiguousarray(rgba8).view(np.uint32).reshape(1, -1)
+    scr = oracle.Screen(flat.ctypes.data, flat.shape[1] // 4, 1, flat.shape[1] * 4)
+    assert f"{int(oracle.load().rco_fnv1a64_words(C.byref(scr), oracle.FNV_BASIS)):016x}" == fx["rgba8_flip_fnv"]
+    culled = pixels(gpu_render(pos, rad, col, cam, w, h, variant=abi.VARIANT_CULLED, scene=scene, ext=ext), w)
+    assert_same_bits(culled, got, "EXT culled vs tiled")
+    if name.startswith("c3"):
+        lit = pixels(gpu_render(pos, rad, col, cam, w, h, variant=abi.VARIANT_LITERAL, scene=scene, ext=ext), w)
+        assert_same_bits(lit, got, "EXT literal vs tiled")
+    scene.free()
+
+
 def test_dropin_execute_kernel_from_reference_call_site(oracle, tmp_path):
     """oracle/_ref/dropin_caller was compiled against the reference's own Screen.h/Scene.h/
     Camera.h and calls execute_kernel(Screen, Scene) by value, as RayTracingKernel.cpp:17."""

@@ -103,8 +103,11 @@ def main():
     if "SQ_ACTIVE_INST_VALU" in avg and "GRBM_GUI_ACTIVE" in avg:
         # SQ_ACTIVE_INST_VALU counts quad-cycles of VALU issue summed over all SIMDs;
         # GRBM_GUI_ACTIVE is summed over the 8 XCDs; 1024 SIMDs
+        # (for launches shorter than ~0.1 ms GRBM_GUI_ACTIVE also covers the gaps around the kernel, so
+        # valu_busy is then a lower bound and no clock can be derived from it)
         derived["valu_busy"] = avg["SQ_ACTIVE_INST_VALU"] * 4 / (avg["GRBM_GUI_ACTIVE"] / 8 * 1024)
-        derived["effective_clock_ghz"] = avg["GRBM_GUI_ACTIVE"] / 8 / (avg["_grbm_pass_ms"] * 1e6)
+        derived["effective_clock_ghz"] = (avg["GRBM_GUI_ACTIVE"] / 8 / (avg["_grbm_pass_ms"] * 1e6)
+                                          if avg["_grbm_pass_ms"] >= 0.1 else None)
     for c, key in (("SQ_LDS_BANK_CONFLICT", "lds_bank_conflict"), ("SQ_INSTS_VALU", "insts_valu"),
                    ("SQ_INSTS_LDS", "insts_lds"), ("SQ_WAVES", "waves")):
         if c in avg:
