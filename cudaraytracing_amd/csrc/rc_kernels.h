@@ -6,6 +6,7 @@
 
 #define RC_CULL_CHUNK_MAX 1024  // culled variant: spheres per pass (see rc_launch_tiled)
 #define RC_LDS_CHUNK_MAX 4096   // most spheres staged in LDS per pass (13 bytes each: 52 KiB)
+#define RC_LDS_EXACT_MAX 1024   // up to this chunk size the exact-test terms are staged too (+16 bytes each)
 
 enum { RC_KVARIANT_AUTO = 0, RC_KVARIANT_LITERAL = 1, RC_KVARIANT_TILED4 = 2, RC_KVARIANT_TILED2 = 3, RC_KVARIANT_TILED8 = 4 };
 
@@ -48,6 +49,7 @@ struct RcKernArgs {
     size_t bins_bytes;
     // filled in by the tiled launcher
     int lds_cap;             // spheres per LDS chunk (multiple of 32)
+    int lds_exact;           // 1: the chunk's exact-test terms {2v, 4c} are staged in LDS as well
     int tiles_x, tiles_y;    // workgroup tiles covering the surface
     int bins_x, bin_q, bin_stride; // bins per row, entries per list segment, bytes per bin
 };

@@ -24,6 +24,7 @@
 
 #include <hip/hip_runtime.h>
 #include <stdint.h>
+#include <stdlib.h>
 #include "rc_kernels.h"
 
 #pragma clang fp contract(off)
@@ -325,13 +326,17 @@ struct RcRecord { float alpha, gamma, beta; bool always; };
 
 constexpr float kNever = -1.0e30f;   // record value that can never reach len
 
-__device__ __forceinline__ RcRecord rc_prepass_sphere(const RcKernArgs &a, int i)
+__device__ __forceinline__ RcRecord rc_prepass_sphere(const RcKernArgs &a, int i, RcExactSphere *exact = nullptr)
 {
     float px = a.position[3 * i + 0], py = a.position[3 * i + 1], pz = a.position[3 * i + 2];
     float r = a.radius[i];
     float vx = a.ox - px, vy = a.oy - py, vz = a.oz - pz;
     float vv = (vx * vx + vy * vy) + vz * vz;
     float c = vv - r * r;                                   // the reference's c, as rounded
+    if (exact) {                                            // the same statements as rc_exact_sphere_from
+        exact->tvx = 2.0f * vx; exact->tvy = 2.0f * vy; exact->tvz = 2.0f * vz;
+        exact->c4 = 4.0f * c;
+    }
     // hardware sqrt / reciprocal (1 ulp each) are enough here: the margins below absorb them
     float thr = __builtin_amdgcn_sqrtf(c) * (1.0f - 0x1p-19f) - 0x1p-17f * __builtin_amdgcn_sqrtf(vv);
     RcRecord rec;
@@ -361,6 +366,10 @@ constexpr int kGroupsPerBlock = kBlockSpheres / kGroup;
 //   uint   flag[cap/4]    per group, byte s = "always" flag of sphere s
 //   int    has_always
 __host__ __device__ constexpr size_t rc_lds_bytes(int cap) { return (size_t)cap * 12 + (size_t)cap + 16; }
+// The brute-force variant appends, when the chunk is small enough to keep the occupancy (lds_exact):
+//   float4 exact[cap]     {2v.x, 2v.y, 2v.z, 4c} of kernel.cu:53-58 per sphere, so that the exact re-test of
+//                         a flagged sphere reads one broadcast b128 instead of going back to global memory
+__host__ __device__ constexpr size_t rc_lds_bytes_exact(int cap) { return rc_lds_bytes(cap) + (size_t)cap * 16; }
 // The culled variant appends: float wg_bounds[4][8] (per-wave tile bounds), ushort list[cap]
 // (indices of the spheres that pass the workgroup-tile test, one segment of cap/4 per wave),
 // int count[4] (entries per segment) and, with bin lists, int id[cap] (scene index of each slot's sphere).
@@ -374,7 +383,7 @@ __host__ __device__ constexpr size_t rc_lds_bytes_cull(int cap, bool with_ids)
 // are wave-uniform.
 template <int P>
 __device__ __forceinline__ void rc_visit_sphere(const RcKernArgs &a, const float *rec, const unsigned char *flagb,
-                                                int j, int sphere, bool lane_forced,
+                                                const float4 *s_exact, int j, int sphere, bool lane_forced,
                                                 const float (&fa)[P], float fb, const float (&len)[P],
                                                 const float (&dx)[P], const float (&dy)[P], const float (&dz)[P],
                                                 float (&minDist)[P], int (&idx)[P])
@@ -390,7 +399,13 @@ __device__ __forceinline__ void rc_visit_sphere(const RcKernArgs &a, const float
         any |= pm[p];
     }
     if (any == 0ull) return;
-    const RcExactSphere e = rc_exact_sphere(a, sphere);
+    RcExactSphere e;
+    if (s_exact) {
+        const float4 v = s_exact[j];
+        e.tvx = v.x; e.tvy = v.y; e.tvz = v.z; e.c4 = v.w;
+    } else {
+        e = rc_exact_sphere(a, sphere);
+    }
     // the exact test only for pixel columns in which some lane still flags the sphere
 #pragma unroll
     for (int p = 0; p < P; p++)
@@ -424,13 +439,17 @@ __device__ __forceinline__ float rc_wave_sum(float v)
 // k(-(v.e)) by <= 7.1ukL, and 1/k = sqrt(c)(1 - 2^-19) - 2^-17 L leaves > 10x that margin.
 struct RcLightRecord { float hx, hy, hz; bool always; };
 
-__device__ __forceinline__ RcLightRecord rc_prepass_light(const RcKernArgs &a, int i)
+__device__ __forceinline__ RcLightRecord rc_prepass_light(const RcKernArgs &a, int i, RcExactSphere *exact = nullptr)
 {
     float px = a.position[3 * i + 0], py = a.position[3 * i + 1], pz = a.position[3 * i + 2];
     float r = a.radius[i];
     float vx = a.lgx - px, vy = a.lgy - py, vz = a.lgz - pz;
     float vv = (vx * vx + vy * vy) + vz * vz;
     float c = vv - r * r;
+    if (exact) {                                            // the same statements as rc_exact_sphere_from
+        exact->tvx = 2.0f * vx; exact->tvy = 2.0f * vy; exact->tvz = 2.0f * vz;
+        exact->c4 = 4.0f * c;
+    }
     float thr = __builtin_amdgcn_sqrtf(c) * (1.0f - 0x1p-19f) - 0x1p-17f * __builtin_amdgcn_sqrtf(vv);
     RcLightRecord rec;
     rec.always = !(c > 0.0f) || !(thr > 0.0f) || !(vv < 0x1p80f) || !(vv > 0x1p-80f);
@@ -465,6 +484,7 @@ __device__ __forceinline__ void rc_shadow_pass(const RcKernArgs &a, char *lds,
     float4 *s_rec = reinterpret_cast<float4 *>(lds);
     unsigned *s_flag = reinterpret_cast<unsigned *>(lds + (size_t)cap * 12);
     int *s_has_always = reinterpret_cast<int *>(lds + (size_t)cap * 13);
+    float4 *s_exact = (!CULL && a.lds_exact) ? reinterpret_cast<float4 *>(lds + rc_lds_bytes(cap)) : nullptr;
     const int tid = threadIdx.x;
 
     bool lane_forced = false;
@@ -513,12 +533,14 @@ __device__ __forceinline__ void rc_shadow_pass(const RcKernArgs &a, char *lds,
             unsigned char *flagb = reinterpret_cast<unsigned char *>(s_flag);
             for (int j = tid; j < cnb; j += kBlock) {
                 RcLightRecord r;
+                RcExactSphere ex = {0.0f, 0.0f, 0.0f, 0.0f};
                 r.hx = 0.0f; r.hy = 0.0f; r.hz = 0.0f; r.always = false;
-                if (j < cn) r = rc_prepass_light(a, base + j);
+                if (j < cn) r = rc_prepass_light(a, base + j, &ex);
                 float *g = rec + (j >> 2) * 12 + (j & 3);
                 g[0] = r.hx; g[4] = r.hy; g[8] = r.hz;
                 flagb[j] = r.always ? 1 : 0;
                 if (r.always) atomicOr(s_has_always, 1);
+                if (s_exact) s_exact[j] = make_float4(ex.tvx, ex.tvy, ex.tvz, ex.c4);
             }
         }
         __syncthreads();
@@ -619,7 +641,13 @@ __device__ __forceinline__ void rc_shadow_pass(const RcKernArgs &a, char *lds,
                     for (int s = 0; s < kGroup; s++) {
                         const int j = gi * kGroup + s;
                         if (cm[s] == 0ull || j >= cn) continue;
-                        const RcExactSphere e = rc_exact_sphere_from(a, base + j, a.lgx, a.lgy, a.lgz);
+                        RcExactSphere e;
+                        if (s_exact) {
+                            const float4 v = s_exact[j];
+                            e.tvx = v.x; e.tvy = v.y; e.tvz = v.z; e.c4 = v.w;
+                        } else {
+                            e = rc_exact_sphere_from(a, base + j, a.lgx, a.lgy, a.lgz);
+                        }
 #pragma unroll
                         for (int p = 0; p < P; p++) {
                             const float dist = rc_exact_dist(e, ex[p], ey[p], ez[p]);
@@ -640,6 +668,7 @@ __device__ __forceinline__ void rc_tiled_body(const RcKernArgs &a, char *lds)
     float4 *s_rec = reinterpret_cast<float4 *>(lds);
     unsigned *s_flag = reinterpret_cast<unsigned *>(lds + (size_t)cap * 12);
     int *s_has_always = reinterpret_cast<int *>(lds + (size_t)cap * 13);
+    float4 *s_exact = (!CULL && a.lds_exact) ? reinterpret_cast<float4 *>(lds + rc_lds_bytes(cap)) : nullptr;
 
     const int tid = threadIdx.x;
     const int wave = tid >> 6, lane = tid & 63;
@@ -798,12 +827,14 @@ __device__ __forceinline__ void rc_tiled_body(const RcKernArgs &a, char *lds)
                 unsigned char *flagb = reinterpret_cast<unsigned char *>(s_flag);
                 for (int j = tid; j < cnb; j += kBlock) {
                     RcRecord r;
+                    RcExactSphere ex = {0.0f, 0.0f, 0.0f, 0.0f};
                     r.alpha = kNever; r.gamma = 0.0f; r.beta = 0.0f; r.always = false;
-                    if (j < cn) r = rc_prepass_sphere(a, base + j);
+                    if (j < cn) r = rc_prepass_sphere(a, base + j, &ex);
                     float *g = rec + (j >> 2) * 12 + (j & 3);
                     g[0] = r.alpha; g[4] = r.gamma; g[8] = r.beta;
                     flagb[j] = r.always ? 1 : 0;
                     if (r.always) atomicOr(s_has_always, 1);
+                    if (s_exact) s_exact[j] = make_float4(ex.tvx, ex.tvy, ex.tvz, ex.c4);
                 }
                 __syncthreads();
             }
@@ -836,7 +867,7 @@ __device__ __forceinline__ void rc_tiled_body(const RcKernArgs &a, char *lds)
                             const int bit = __builtin_ctzll(cand_mask);
                             cand_mask &= cand_mask - 1ull;
                             const int j = __builtin_amdgcn_readlane(jl, bit);
-                            rc_visit_sphere<P>(a, rec, flagb, j, BINS ? s_id[j] : base + j, lane_forced, fa, fb, len,
+                            rc_visit_sphere<P>(a, rec, flagb, nullptr, j, BINS ? s_id[j] : base + j, lane_forced, fa, fb, len,
                                                dx, dy, dz, minDist, idx);
                         }
                     }
@@ -887,7 +918,7 @@ __device__ __forceinline__ void rc_tiled_body(const RcKernArgs &a, char *lds)
                     while (cand_mask != 0ull) {
                         const int bit = __builtin_ctzll(cand_mask);
                         cand_mask &= cand_mask - 1ull;
-                        rc_visit_sphere<P>(a, rec, flagb, blk * kBlockSpheres + bit, base + blk * kBlockSpheres + bit, lane_forced, fa, fb, len,
+                        rc_visit_sphere<P>(a, rec, flagb, s_exact, blk * kBlockSpheres + bit, base + blk * kBlockSpheres + bit, lane_forced, fa, fb, len,
                                            dx, dy, dz, minDist, idx);
                     }
                 }
@@ -1047,6 +1078,13 @@ __global__ __launch_bounds__(256) void rc_rgba8_kernel(const char *surface, size
 // Launchers (host)
 // ---------------------------------------------------------------------------------------
 
+// tuning switch for A/B runs: NAME=0 in the environment turns a default-on feature off
+static bool rc_env_off(const char *name)
+{
+    const char *v = getenv(name);
+    return v && v[0] == '0';
+}
+
 template <int P>
 static long long rc_tile_count(const RcKernArgs &a)
 {
@@ -1065,6 +1103,9 @@ static hipError_t rc_launch_tiled(RcKernArgs a, hipStream_t stream)
     if (a.cull && a.lds_cap > RC_CULL_CHUNK_MAX) a.lds_cap = RC_CULL_CHUNK_MAX;
     a.tiles_x = (a.width + 16 * P - 1) / (16 * P);
     a.tiles_y = (a.rows + 15) / 16;
+    static const bool exact_off = rc_env_off("RC_LDS_EXACT");     // read once
+    a.lds_exact = (!a.cull && a.lds_cap <= RC_LDS_EXACT_MAX && !exact_off) ? 1 : 0;
+    const size_t lds_plain = a.lds_exact ? rc_lds_bytes_exact(a.lds_cap) : rc_lds_bytes(a.lds_cap);
     const unsigned grid = (unsigned)rc_tile_count<P>(a);
     if (a.cull && a.bins) {
         // level 0: bins of 4 x 4 workgroup tiles; layout fixed here because it depends on P
@@ -1085,14 +1126,14 @@ static hipError_t rc_launch_tiled(RcKernArgs a, hipStream_t stream)
         if constexpr (P <= 4) {
             if (a.cull && a.bins) hipLaunchKernelGGL((rc_draw_tiled<P, true, true, true>), dim3(grid), dim3(256), rc_lds_bytes_cull(a.lds_cap, true), stream, a);
             else if (a.cull) hipLaunchKernelGGL((rc_draw_tiled<P, true, true>), dim3(grid), dim3(256), rc_lds_bytes_cull(a.lds_cap, false), stream, a);
-            else hipLaunchKernelGGL((rc_draw_tiled<P, true, false>), dim3(grid), dim3(256), rc_lds_bytes(a.lds_cap), stream, a);
+            else hipLaunchKernelGGL((rc_draw_tiled<P, true, false>), dim3(grid), dim3(256), lds_plain, stream, a);
         } else {
             return hipErrorInvalidValue;           // EXT is built for <= 4 pixels per lane
         }
     } else {
         if (a.cull && a.bins) hipLaunchKernelGGL((rc_draw_tiled<P, false, true, true>), dim3(grid), dim3(256), rc_lds_bytes_cull(a.lds_cap, true), stream, a);
         else if (a.cull) hipLaunchKernelGGL((rc_draw_tiled<P, false, true>), dim3(grid), dim3(256), rc_lds_bytes_cull(a.lds_cap, false), stream, a);
-        else hipLaunchKernelGGL((rc_draw_tiled<P, false, false>), dim3(grid), dim3(256), rc_lds_bytes(a.lds_cap), stream, a);
+        else hipLaunchKernelGGL((rc_draw_tiled<P, false, false>), dim3(grid), dim3(256), lds_plain, stream, a);
     }
     return hipGetLastError();
 }
