@@ -66,6 +66,7 @@ def parse():
                     help="also capture the K steps into one HIP graph and time its replay (reported as graph_replay, never as value)")
     ap.add_argument("--no-extras", action="store_true",
                     help="only the headline measurement: no culled_variant / display_conversion legs (for profiling runs)")
+    ap.add_argument("--tuning", type=int, default=0, help="rc_opts.tuning bits (RC_TUNE_*): launcher overrides for A/B runs")
     ap.add_argument("--no-cpu", action="store_true", help="skip the cpu_baseline leg")
     ap.add_argument("--no-clock-ramp", action="store_true",
                     help="do not extend the untimed warm-up until the GPU has reached its steady clock")
@@ -307,7 +308,7 @@ def main():
     frame = torch.empty((rows, w, 4), dtype=torch.float32, device="cuda")
     screen = abi.RcScreen(frame.data_ptr(), w, rows, w * 16)
     stream = torch.cuda.current_stream().cuda_stream
-    opts = abi.RcOpts(y_offset=y0, full_height=h, variant=variant, stream=stream)
+    opts = abi.RcOpts(y_offset=y0, full_height=h, variant=variant, stream=stream, tuning=args.tuning)
     rc_ext = None
     if args.shading == "ext":
         rc_ext = abi.RcExt(**{k: (abi.RcVec3(*v) if isinstance(v, tuple) else v) for k, v in configs.DEFAULT_EXT.items()})
@@ -606,7 +607,7 @@ def main():
             "vs_baseline": None, "dtype": "f32", "data": "synthetic",
             "config": {"workload": args.config, "width": w, "height": h, "spheres": n,
                        "mode": "REF" if args.shading == "ref" else "EXT (plane + point light + Phong + hard shadows; unpinned by the reference)",
-                       "variant": args.variant, "sharding": args.mode, "gathered": (args.gather if banded else None), "backend": backend if world > 1 else None,
+                       "variant": args.variant, "tuning": args.tuning, "sharding": args.mode, "gathered": (args.gather if banded else None), "backend": backend if world > 1 else None,
                        "camera": "sequence" if args.sequence else "static",
                        "device": name.value.decode(), "compute_units": cu.value, "clock_mhz": khz.value / 1e3},
             "frame_ms": kernel_ms, "frame_ms_stats": frame_stats, "per_rank_step_ms": per_rank_ms, "gather_check": gather_check,

@@ -9,6 +9,8 @@ import os
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "librc_hip.so")
 
+ABI_VERSION = 2     # RC_ABI_VERSION of include/rc_abi.h this binding was written against
+
 RC_OK = 0
 RC_EINVAL = -100001
 
@@ -50,7 +52,7 @@ class RcExt(C.Structure):
 class RcOpts(C.Structure):
     _fields_ = [("y_offset", C.c_int), ("full_height", C.c_int), ("variant", C.c_int),
                 ("mode", C.c_int), ("stream", C.c_void_p), ("rgba8", C.c_void_p),
-                ("rgba8_pitch", C.c_size_t), ("rgba8_flip", C.c_int), ("reserved1", C.c_int),
+                ("rgba8_pitch", C.c_size_t), ("rgba8_flip", C.c_int), ("tuning", C.c_int),
                 ("ext", C.POINTER(RcExt)), ("workspace", C.c_void_p), ("workspace_bytes", C.c_size_t)]
 
 
@@ -60,6 +62,10 @@ class RcInput(C.Structure):
                 ("key_w", C.c_int), ("key_a", C.c_int), ("key_s", C.c_int), ("key_d", C.c_int),
                 ("cursor_dx", C.c_int), ("cursor_dy", C.c_int)]
 
+
+TUNE_SHADOW_AXIS_ON = 1
+TUNE_SHADOW_AXIS_OFF = 2
+TUNE_NO_LDS_EXACT = 4
 
 MODE_REF = 0
 MODE_EXT = 1
@@ -122,6 +128,7 @@ SYMBOLS = {
     "rc_write_ppm": (C.c_int, [C.c_char_p, C.c_void_p, C.c_size_t, C.c_int, C.c_int]),
     "rc_last_error_string": (C.c_char_p, []),
     "rc_version": (C.c_char_p, []),
+    "rc_abi_version": (C.c_int, []),
     # the source-level drop-in (kernel.cu:114-115); C++ by-value convention, so it is only
     # checked for presence here and exercised by the C++ caller in tests/
     "execute_kernel": (None, None),
@@ -149,6 +156,9 @@ def load():
         if argtypes is not None:
             fn.restype = restype
             fn.argtypes = argtypes
+    if lib.rc_abi_version() != ABI_VERSION:
+        raise RcError(f"{LIB_PATH} was built for ABI version {lib.rc_abi_version()}, this binding needs {ABI_VERSION}: "
+                      "rebuild it with `python -m cudaraytracing_amd.build`")
     _lib = lib
     return lib
 

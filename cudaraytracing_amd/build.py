@@ -43,10 +43,22 @@ def hipcc_path():
 def build(force=False, verbose=False):
     """Compile librc_hip.so and the rc_render CLI if missing or stale. Returns the .so path."""
     if force or _stale(LIB_PATH, SOURCES + HEADERS):
-        cmd = [hipcc_path()] + HIPCC_FLAGS + ["-shared", "-o", LIB_PATH] + SOURCES
+        # A library older than its sources must never survive a failed build (it would travel to the GPU
+        # box and run there against newer bindings and tests): it is removed first and the new one is
+        # moved into place only when the compiler succeeded.
+        for stale in (LIB_PATH, CLI_PATH):
+            if os.path.exists(stale):
+                os.remove(stale)
+        tmp = LIB_PATH + ".tmp"
+        cmd = [hipcc_path()] + HIPCC_FLAGS + ["-shared", "-o", tmp] + SOURCES
         if verbose:
             print(" ".join(cmd))
-        subprocess.run(cmd, check=True, cwd=_ROOT)
+        try:
+            subprocess.run(cmd, check=True, cwd=_ROOT)
+            os.replace(tmp, LIB_PATH)
+        finally:
+            if os.path.exists(tmp):
+                os.remove(tmp)
     cli_src = os.path.join(CSRC, "host", "rc_render_main.cpp")
     cli_deps = [cli_src, LIB_PATH] + [
         os.path.join(CSRC, "host", h) for h in ("rc_camera.hpp", "rc_scene_manager.hpp", "rc_raycaster.hpp", "rc_frame_pipeline.hpp")

@@ -28,6 +28,8 @@ static_assert(sizeof(rc_ext) == 56, "rc_ext layout");
 static_assert(sizeof(rc_opts) == 72 && offsetof(rc_opts, stream) == 16 && offsetof(rc_opts, ext) == 48 &&
               offsetof(rc_opts, workspace) == 56, "rc_opts layout (mirrored by the ctypes binding)");
 static_assert(sizeof(rc_input) == 40, "rc_input layout");
+static_assert(RC_TUNE_SHADOW_AXIS_ON == RC_KTUNE_SHADOW_AXIS_ON && RC_TUNE_SHADOW_AXIS_OFF == RC_KTUNE_SHADOW_AXIS_OFF &&
+              RC_TUNE_NO_LDS_EXACT == RC_KTUNE_NO_LDS_EXACT, "tuning bits");
 static_assert(offsetof(rc_scene, position) == 8 && offsetof(rc_scene, radius) == 16 &&
               offsetof(rc_scene, color) == 24 && offsetof(rc_scene, cam) == 32, "Scene.h field offsets");
 static_assert(offsetof(rc_screen, width) == 8 && offsetof(rc_screen, height) == 12 &&
@@ -209,6 +211,7 @@ int rc_check_render_args(const rc_screen *screen, const rc_scene *scene, const r
         return rc_fail_arg("rgba8 surface must be 4-byte aligned with pitch >= 4*width, multiple of 4");
 
     if (o.mode != RC_MODE_REF && o.mode != RC_MODE_EXT) return rc_fail_arg("unknown mode");
+    if (o.tuning & ~(RC_TUNE_SHADOW_AXIS_ON | RC_TUNE_SHADOW_AXIS_OFF | RC_TUNE_NO_LDS_EXACT)) return rc_fail_arg("unknown tuning bits");
     if (o.mode == RC_MODE_EXT) {
         if (!o.ext) return rc_fail_arg("mode EXT needs opts->ext");
         if (o.ext->shininess_log2 < 0 || o.ext->shininess_log2 > 30) return rc_fail_arg("shininess_log2 must be 0..30");
@@ -249,6 +252,7 @@ int rc_enqueue_frame(const rc_screen *screen, const rc_scene *scene, const rc_op
     a.rgba8_pitch = o.rgba8_pitch;
     a.rgba8_flip = o.rgba8_flip;
     a.cull = (o.variant == RC_VARIANT_CULLED) ? 1 : 0;
+    a.tuning = o.tuning;
     a.aspect = scene->cam.aspect;
     a.ox = scene->cam.position.x; a.oy = scene->cam.position.y; a.oz = scene->cam.position.z;
     a.fx = scene->cam.forward.x;  a.fy = scene->cam.forward.y;  a.fz = scene->cam.forward.z;
@@ -790,7 +794,9 @@ extern "C" int rc_write_ppm(const char *path, const uint8_t *rgba8, size_t pitch
 
 extern "C" const char *rc_last_error_string(void) { return g_err; }
 
-extern "C" const char *rc_version(void) { return "rc_hip 0.1 gfx950"; }
+extern "C" const char *rc_version(void) { return "rc_hip 0.2 gfx950"; }
+
+extern "C" int rc_abi_version(void) { return RC_ABI_VERSION; }
 
 // ---- context API: the C++ host classes (csrc/host/*.hpp) behind C entry points ----------------
 #include "host/rc_raycaster.hpp"

@@ -6,8 +6,11 @@
 
 #define RC_CULL_CHUNK_MAX 1024  // culled variant: spheres per pass (see rc_launch_tiled)
 #define RC_LDS_CHUNK_MAX 4096   // most spheres staged in LDS per pass (13 bytes each: 52 KiB)
+#define RC_SHADOW_FAST_MIN 1024  // EXT: from this many spheres the shadow pass uses its dominant-axis filter
 #define RC_LDS_EXACT_MAX 1024   // up to this chunk size the exact-test terms are staged too (+16 bytes each)
 
+// rc_opts.tuning bits as the launchers see them (same values as RC_TUNE_* in rc_abi.h)
+enum { RC_KTUNE_SHADOW_AXIS_ON = 1, RC_KTUNE_SHADOW_AXIS_OFF = 2, RC_KTUNE_NO_LDS_EXACT = 4 };
 enum { RC_KVARIANT_AUTO = 0, RC_KVARIANT_LITERAL = 1, RC_KVARIANT_TILED4 = 2, RC_KVARIANT_TILED2 = 3, RC_KVARIANT_TILED8 = 4 };
 
 // Passed by value as the kernel parameter, as the reference passes Screen and Scene
@@ -36,6 +39,7 @@ struct RcKernArgs {
     float nF, nR, nU;        // upper bounds of |forward|, |right|, |up| (filter range check)
     int cam_ok;              // 0: camera basis outside the range the filter is proven for
     // EXT mode (plane + point light + Phong + hard shadows; no counterpart in the reference)
+    int tuning;              // RC_KTUNE_* bits
     int cull;                // 1: tile-culling variant of the tiled kernel
     int ext_mode;            // 0: the reference's shading; 1: EXT
     int has_plane, shadows, shininess_log2;
@@ -50,6 +54,7 @@ struct RcKernArgs {
     // filled in by the tiled launcher
     int lds_cap;             // spheres per LDS chunk (multiple of 32)
     int lds_exact;           // 1: the chunk's exact-test terms {2v, 4c} are staged in LDS as well
+    int shadow_fast;         // 1: launch the kernel whose EXT shadow pass may use the dominant-axis filter (set by the launcher)
     int tiles_x, tiles_y;    // workgroup tiles covering the surface
     int bins_x, bin_q, bin_stride; // bins per row, entries per list segment, bytes per bin
 };

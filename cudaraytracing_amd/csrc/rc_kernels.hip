@@ -24,7 +24,6 @@
 
 #include <hip/hip_runtime.h>
 #include <stdint.h>
-#include <stdlib.h>
 #include "rc_kernels.h"
 
 #pragma clang fp contract(off)
@@ -460,6 +459,112 @@ __device__ __forceinline__ RcLightRecord rc_prepass_light(const RcKernArgs &a, i
     return rec;
 }
 
+// Brute-force blocks of the shadow pass over one LDS chunk: every (hit pixel, sphere) pair gets the
+// conservative filter, flagged spheres the exact test.
+//
+// FAST = false: the records hold h = (hx, hy, hz) and the filter is T = h.e >= 1 (mul + two FMAs).
+//
+// FAST = true: all shadow rays of the WORKGROUP share a dominant axis m and sign s with g = s e_m >= 1/2
+// (rays of neighbouring pixels start at one light and end close together, so this is the normal case).
+// Dividing h.e >= 1 by g > 0 gives
+//      s h_m + u h_j + v h_k  >=  1/g,        u = e_j / g,  v = e_k / g     (j, k the other two axes)
+// so with records (s h_m, h_j, h_k) the filter is T = fma(u, R1, fma(v, R2, R0)) >= len, two FMAs per
+// pair instead of three.  Soundness on top of the bound at rc_prepass_light (an exact hit implies, in
+// real numbers, h.e >= 1 + S with S >= 2^-19 + 0.97 2^-17 |h|; u = 2^-24): |u|, |v| <= sqrt(3) because
+// g >= 1/2 and |e| = 1 within 3u; il = rcp(g) is within 2u of 1/g (1-ulp hardware reciprocal), so the
+// float u, v are within 3u; the two FMAs then differ from the real T by at most
+// u (4|v||h_k| + |h_m| + 3|u||h_j| + |T|) <= 17.7 u |h|; the threshold il (1 - 2^-21) is below
+// (1 + S)/g - (S - 2u).  Needed: S - 2u - 17.7 u |h| >= 0, which holds with a factor of 6 to spare.
+// Pixels without a shadow ray carry u = v = 0 and len = +inf (never flagged); forced lanes and
+// "always" spheres bypass the filter in both forms.
+template <int P, bool FAST>
+__device__ __forceinline__ void rc_shadow_blocks(const RcKernArgs &a, const float4 *s_rec, const unsigned *s_flag,
+                                                 const float4 *s_exact, int base, int cn, int nblocks,
+                                                 unsigned long long flag0_mask, unsigned long long forced_mask,
+                                                 const float (&fu)[P], const float (&fv)[P], const float (&flen)[P],
+                                                 const float (&ex)[P], const float (&ey)[P], const float (&ez)[P],
+                                                 const float (&limit)[P], const int (&idx)[P], unsigned &shadowed)
+{
+    for (int blk = 0; blk < nblocks; blk++) {
+        float m[P];
+#pragma unroll
+        for (int p = 0; p < P; p++) m[p] = FAST ? -__builtin_inff() : 0.0f;
+#pragma unroll
+        for (int g = 0; g < kGroupsPerBlock; g++) {
+            const float4 H0 = s_rec[(blk * kGroupsPerBlock + g) * 3 + 0];
+            const float4 H1 = s_rec[(blk * kGroupsPerBlock + g) * 3 + 1];
+            const float4 H2 = s_rec[(blk * kGroupsPerBlock + g) * 3 + 2];
+#pragma unroll
+            for (int p = 0; p < P; p++) {
+                rc_f2 f01, f23;
+                if (FAST) {
+                    const rc_f2 uu = {fu[p], fu[p]}, vv = {fv[p], fv[p]};
+                    f01 = rc_fma2(uu, rc_f2{H1.x, H1.y}, rc_fma2(vv, rc_f2{H2.x, H2.y}, rc_f2{H0.x, H0.y}));
+                    f23 = rc_fma2(uu, rc_f2{H1.z, H1.w}, rc_fma2(vv, rc_f2{H2.z, H2.w}, rc_f2{H0.z, H0.w}));
+                } else {
+                    const rc_f2 e0 = {ex[p], ex[p]}, e1 = {ey[p], ey[p]}, e2 = {ez[p], ez[p]};
+                    f01 = rc_fma2(e2, rc_f2{H2.x, H2.y}, rc_fma2(e1, rc_f2{H1.x, H1.y}, e0 * rc_f2{H0.x, H0.y}));
+                    f23 = rc_fma2(e2, rc_f2{H2.z, H2.w}, rc_fma2(e1, rc_f2{H1.z, H1.w}, e0 * rc_f2{H0.z, H0.w}));
+                }
+                m[p] = fmaxf(fmaxf(m[p], f01.x), f01.y);
+                m[p] = fmaxf(fmaxf(m[p], f23.x), f23.y);
+            }
+        }
+        unsigned long long flagged = flag0_mask;
+#pragma unroll
+        for (int p = 0; p < P; p++) flagged |= __builtin_amdgcn_ballot_w64(m[p] >= (FAST ? flen[p] : 1.0f));
+        if (flagged != 0ull) {
+#pragma nounroll
+            for (int g = 0; g < kGroupsPerBlock; g++) {
+                const int gi = blk * kGroupsPerBlock + g;
+                if (gi * kGroup >= cn) break;
+                const float4 H0 = s_rec[gi * 3 + 0];
+                const float4 H1 = s_rec[gi * 3 + 1];
+                const float4 H2 = s_rec[gi * 3 + 2];
+                const unsigned fl = __builtin_amdgcn_readfirstlane(s_flag[gi]);
+                unsigned long long cm[kGroup];
+#pragma unroll
+                for (int s = 0; s < kGroup; s++) cm[s] = ((fl >> (8 * s)) & 0xffu) ? ~0ull : forced_mask;
+#pragma unroll
+                for (int p = 0; p < P; p++) {
+                    rc_f2 f01, f23;
+                    if (FAST) {
+                        const rc_f2 uu = {fu[p], fu[p]}, vv = {fv[p], fv[p]};
+                        f01 = rc_fma2(uu, rc_f2{H1.x, H1.y}, rc_fma2(vv, rc_f2{H2.x, H2.y}, rc_f2{H0.x, H0.y}));
+                        f23 = rc_fma2(uu, rc_f2{H1.z, H1.w}, rc_fma2(vv, rc_f2{H2.z, H2.w}, rc_f2{H0.z, H0.w}));
+                    } else {
+                        const rc_f2 e0 = {ex[p], ex[p]}, e1 = {ey[p], ey[p]}, e2 = {ez[p], ez[p]};
+                        f01 = rc_fma2(e2, rc_f2{H2.x, H2.y}, rc_fma2(e1, rc_f2{H1.x, H1.y}, e0 * rc_f2{H0.x, H0.y}));
+                        f23 = rc_fma2(e2, rc_f2{H2.z, H2.w}, rc_fma2(e1, rc_f2{H1.z, H1.w}, e0 * rc_f2{H0.z, H0.w}));
+                    }
+                    const float thr = FAST ? flen[p] : 1.0f;
+                    cm[0] |= __builtin_amdgcn_ballot_w64(f01.x >= thr);
+                    cm[1] |= __builtin_amdgcn_ballot_w64(f01.y >= thr);
+                    cm[2] |= __builtin_amdgcn_ballot_w64(f23.x >= thr);
+                    cm[3] |= __builtin_amdgcn_ballot_w64(f23.y >= thr);
+                }
+#pragma unroll
+                for (int s = 0; s < kGroup; s++) {
+                    const int j = gi * kGroup + s;
+                    if (cm[s] == 0ull || j >= cn) continue;
+                    RcExactSphere e;
+                    if (s_exact) {
+                        const float4 v = s_exact[j];
+                        e.tvx = v.x; e.tvy = v.y; e.tvz = v.z; e.c4 = v.w;
+                    } else {
+                        e = rc_exact_sphere_from(a, base + j, a.lgx, a.lgy, a.lgz);
+                    }
+#pragma unroll
+                    for (int p = 0; p < P; p++) {
+                        const float dist = rc_exact_dist(e, ex[p], ey[p], ez[p]);
+                        if (base + j != idx[p] && dist > 0.0f && dist < limit[p]) shadowed |= 1u << p;
+                    }
+                }
+            }
+        }
+    }
+}
+
 // Hard-shadow pass of EXT mode: for every hit pixel, is any sphere other than the one hit
 // between the light and the point?  Same structure as the primary search (LDS records,
 // conservative FMA filter, exact re-test of what the filter cannot rule out); the rays share
@@ -475,10 +580,10 @@ __device__ __forceinline__ RcLightRecord rc_prepass_light(const RcKernArgs &a, i
 // test.  The cone is widened (cos phi lowered by 2^-18, the perpendicular part of h raised by
 // 2^-10 |h|, the bound by 2^-16) well beyond the float errors of its own evaluation, and tiles
 // whose rays do not fit a cone narrower than 90 degrees test every sphere.
-template <int P, bool CULL>
+template <int P, bool CULL, bool SHFAST>
 __device__ __forceinline__ void rc_shadow_pass(const RcKernArgs &a, char *lds,
                                                const float (&ex)[P], const float (&ey)[P], const float (&ez)[P],
-                                               const float (&limit)[P], const int (&idx)[P], bool (&shadowed)[P])
+                                               const float (&limit)[P], const int (&idx)[P], unsigned &shadowed)
 {
     const int cap = a.lds_cap;
     float4 *s_rec = reinterpret_cast<float4 *>(lds);
@@ -522,6 +627,49 @@ __device__ __forceinline__ void rc_shadow_pass(const RcKernArgs &a, char *lds,
         csin = __builtin_amdgcn_sqrtf(fmaxf(__builtin_fmaf(-ccos, ccos, 1.0f), 0.0f)) * (1.0f + 0x1p-18f) + 0x1p-20f;
     }
 
+    // Brute-force variant: does the whole workgroup share a dominant shadow-ray axis (see rc_shadow_blocks)?
+    int fast_axis = -1;
+    float fast_sign = 1.0f;
+    float fu[P], fv[P], flen[P];
+#pragma unroll
+    for (int p = 0; p < P; p++) { fu[p] = 0.0f; fv[p] = 0.0f; flen[p] = __builtin_inff(); }
+    if (!CULL && SHFAST) {
+        __shared__ unsigned s_axis[4];
+        // bit k of `ok`: candidate k = (axis k >> 1, sign k & 1 ? -1 : +1) has s e_m >= 1/2 for every shadow
+        // ray of this wave (a wave without shadow rays accepts every candidate)
+        unsigned ok = 0u;
+#pragma unroll
+        for (int k = 0; k < 6; k++) {
+            bool bad = false;
+#pragma unroll
+            for (int p = 0; p < P; p++) {
+                const float em = (k >> 1) == 0 ? ex[p] : ((k >> 1) == 1 ? ey[p] : ez[p]);
+                bad = bad || (idx[p] != -1 && !(((k & 1) ? -em : em) >= 0.5f));
+            }
+            if (__builtin_amdgcn_ballot_w64(bad) == 0ull) ok |= 1u << k;
+        }
+        if ((tid & 63) == 0) s_axis[tid >> 6] = ok;
+        __syncthreads();
+        ok = s_axis[0] & s_axis[1] & s_axis[2] & s_axis[3];
+        if (ok != 0u) {
+            const int bk = __builtin_ctz(ok);
+            fast_axis = bk >> 1;
+            fast_sign = (bk & 1) ? -1.0f : 1.0f;
+#pragma unroll
+            for (int p = 0; p < P; p++) {
+                if (idx[p] != -1) {
+                    const float em = fast_axis == 0 ? ex[p] : (fast_axis == 1 ? ey[p] : ez[p]);
+                    const float ej = fast_axis == 0 ? ey[p] : (fast_axis == 1 ? ez[p] : ex[p]);
+                    const float ek = fast_axis == 0 ? ez[p] : (fast_axis == 1 ? ex[p] : ey[p]);
+                    const float il = __builtin_amdgcn_rcpf(fast_sign * em);
+                    fu[p] = ej * il;
+                    fv[p] = ek * il;
+                    flen[p] = il * (1.0f - 0x1p-21f);
+                }
+            }
+        }
+    }
+
     for (int base = 0; base < a.n; base += cap) {
         const int cn = min(a.n - base, cap);
         const int cnb = (cn + kBlockSpheres - 1) & ~(kBlockSpheres - 1);
@@ -536,6 +684,12 @@ __device__ __forceinline__ void rc_shadow_pass(const RcKernArgs &a, char *lds,
                 RcExactSphere ex = {0.0f, 0.0f, 0.0f, 0.0f};
                 r.hx = 0.0f; r.hy = 0.0f; r.hz = 0.0f; r.always = false;
                 if (j < cn) r = rc_prepass_light(a, base + j, &ex);
+                if (fast_axis >= 0) {              // (s h_m, h_j, h_k) for the workgroup's dominant axis m
+                    const float hm = fast_axis == 0 ? r.hx : (fast_axis == 1 ? r.hy : r.hz);
+                    const float hj = fast_axis == 0 ? r.hy : (fast_axis == 1 ? r.hz : r.hx);
+                    const float hk = fast_axis == 0 ? r.hz : (fast_axis == 1 ? r.hx : r.hy);
+                    r.hx = fast_sign * hm; r.hy = hj; r.hz = hk;
+                }
                 float *g = rec + (j >> 2) * 12 + (j & 3);
                 g[0] = r.hx; g[4] = r.hy; g[8] = r.hz;
                 flagb[j] = r.always ? 1 : 0;
@@ -588,79 +742,24 @@ __device__ __forceinline__ void rc_shadow_pass(const RcKernArgs &a, char *lds,
                     for (int p = 0; p < P; p++) {
                         if (pm[p] == 0ull) continue;
                         const float dist = rc_exact_dist(e, ex[p], ey[p], ez[p]);
-                        if (base + j != idx[p] && dist > 0.0f && dist < limit[p]) shadowed[p] = true;
+                        if (base + j != idx[p] && dist > 0.0f && dist < limit[p]) shadowed |= 1u << p;
                     }
                 }
             }
         }
 
-        for (int blk = 0; blk < nblocks; blk++) {
-            float m[P];
-#pragma unroll
-            for (int p = 0; p < P; p++) m[p] = 0.0f;
-#pragma unroll
-            for (int g = 0; g < kGroupsPerBlock; g++) {
-                const float4 HX = s_rec[(blk * kGroupsPerBlock + g) * 3 + 0];
-                const float4 HY = s_rec[(blk * kGroupsPerBlock + g) * 3 + 1];
-                const float4 HZ = s_rec[(blk * kGroupsPerBlock + g) * 3 + 2];
-#pragma unroll
-                for (int p = 0; p < P; p++) {
-                    const rc_f2 e0 = {ex[p], ex[p]}, e1 = {ey[p], ey[p]}, e2 = {ez[p], ez[p]};
-                    const rc_f2 f01 = rc_fma2(e2, rc_f2{HZ.x, HZ.y}, rc_fma2(e1, rc_f2{HY.x, HY.y}, e0 * rc_f2{HX.x, HX.y}));
-                    const rc_f2 f23 = rc_fma2(e2, rc_f2{HZ.z, HZ.w}, rc_fma2(e1, rc_f2{HY.z, HY.w}, e0 * rc_f2{HX.z, HX.w}));
-                    m[p] = fmaxf(fmaxf(m[p], f01.x), f01.y);
-                    m[p] = fmaxf(fmaxf(m[p], f23.x), f23.y);
-                }
-            }
-            unsigned long long flagged = flag0_mask;
-#pragma unroll
-            for (int p = 0; p < P; p++) flagged |= __builtin_amdgcn_ballot_w64(m[p] >= 1.0f);
-            if (flagged != 0ull) {
-#pragma nounroll
-                for (int g = 0; g < kGroupsPerBlock; g++) {
-                    const int gi = blk * kGroupsPerBlock + g;
-                    if (gi * kGroup >= cn) break;
-                    const float4 HX = s_rec[gi * 3 + 0];
-                    const float4 HY = s_rec[gi * 3 + 1];
-                    const float4 HZ = s_rec[gi * 3 + 2];
-                    const unsigned fl = __builtin_amdgcn_readfirstlane(s_flag[gi]);
-                    unsigned long long cm[kGroup];
-#pragma unroll
-                    for (int s = 0; s < kGroup; s++) cm[s] = ((fl >> (8 * s)) & 0xffu) ? ~0ull : forced_mask;
-#pragma unroll
-                    for (int p = 0; p < P; p++) {
-                        const rc_f2 e0 = {ex[p], ex[p]}, e1 = {ey[p], ey[p]}, e2 = {ez[p], ez[p]};
-                        const rc_f2 f01 = rc_fma2(e2, rc_f2{HZ.x, HZ.y}, rc_fma2(e1, rc_f2{HY.x, HY.y}, e0 * rc_f2{HX.x, HX.y}));
-                        const rc_f2 f23 = rc_fma2(e2, rc_f2{HZ.z, HZ.w}, rc_fma2(e1, rc_f2{HY.z, HY.w}, e0 * rc_f2{HX.z, HX.w}));
-                        cm[0] |= __builtin_amdgcn_ballot_w64(f01.x >= 1.0f);
-                        cm[1] |= __builtin_amdgcn_ballot_w64(f01.y >= 1.0f);
-                        cm[2] |= __builtin_amdgcn_ballot_w64(f23.x >= 1.0f);
-                        cm[3] |= __builtin_amdgcn_ballot_w64(f23.y >= 1.0f);
-                    }
-#pragma unroll
-                    for (int s = 0; s < kGroup; s++) {
-                        const int j = gi * kGroup + s;
-                        if (cm[s] == 0ull || j >= cn) continue;
-                        RcExactSphere e;
-                        if (s_exact) {
-                            const float4 v = s_exact[j];
-                            e.tvx = v.x; e.tvy = v.y; e.tvz = v.z; e.c4 = v.w;
-                        } else {
-                            e = rc_exact_sphere_from(a, base + j, a.lgx, a.lgy, a.lgz);
-                        }
-#pragma unroll
-                        for (int p = 0; p < P; p++) {
-                            const float dist = rc_exact_dist(e, ex[p], ey[p], ez[p]);
-                            if (base + j != idx[p] && dist > 0.0f && dist < limit[p]) shadowed[p] = true;
-                        }
-                    }
-                }
-            }
+        if (!CULL && nblocks > 0) {
+            if (SHFAST && fast_axis >= 0)
+                rc_shadow_blocks<P, true>(a, s_rec, s_flag, s_exact, base, cn, nblocks, flag0_mask, forced_mask,
+                                          fu, fv, flen, ex, ey, ez, limit, idx, shadowed);
+            else
+                rc_shadow_blocks<P, false>(a, s_rec, s_flag, s_exact, base, cn, nblocks, flag0_mask, forced_mask,
+                                           fu, fv, flen, ex, ey, ez, limit, idx, shadowed);
         }
     }
 }
 
-template <int P, bool EXT, bool CULL, bool BINS>
+template <int P, bool EXT, bool CULL, bool BINS, bool SHFAST>
 __device__ __forceinline__ void rc_tiled_body(const RcKernArgs &a, char *lds)
 {
     constexpr int TW = 8 * P;   // wave tile width in pixels
@@ -925,9 +1024,7 @@ __device__ __forceinline__ void rc_tiled_body(const RcKernArgs &a, char *lds)
             }
         }
 
-        bool shadowed[P];
-#pragma unroll
-        for (int p = 0; p < P; p++) shadowed[p] = false;
+        unsigned shadowed = 0u;                     // bit p: pixel p of this lane is in shadow
         if (EXT) {
 #pragma unroll
             for (int p = 0; p < P; p++) rc_plane_test(a, dx[p], dy[p], dz[p], minDist[p], idx[p]);
@@ -938,10 +1035,10 @@ __device__ __forceinline__ void rc_tiled_body(const RcKernArgs &a, char *lds)
                     ex[p] = 0.0f; ey[p] = 0.0f; ez[p] = 0.0f; limit[p] = -1.0f;   // misses cast no shadow ray
                     if (idx[p] != -1) rc_ext_ray(a, minDist[p], dx[p], dy[p], dz[p], ex[p], ey[p], ez[p], limit[p]);
                 }
-                rc_shadow_pass<P, CULL>(a, lds, ex, ey, ez, limit, idx, shadowed);
+                rc_shadow_pass<P, CULL, SHFAST>(a, lds, ex, ey, ez, limit, idx, shadowed);
 #pragma unroll
                 for (int p = 0; p < P; p++)
-                    if (idx[p] != -1 && rc_plane_shadow(a, idx[p], ex[p], ey[p], ez[p], limit[p])) shadowed[p] = true;
+                    if (idx[p] != -1 && rc_plane_shadow(a, idx[p], ex[p], ey[p], ez[p], limit[p])) shadowed |= 1u << p;
             }
         }
 
@@ -952,7 +1049,17 @@ __device__ __forceinline__ void rc_tiled_body(const RcKernArgs &a, char *lds)
                 if (x < a.width) {
                     float r = 0.0f, g = 0.0f, b = 0.0f;
                     if (EXT) {
-                        if (idx[p] != -1) rc_ext_shade(a, idx[p], minDist[p], dx[p], dy[p], dz[p], shadowed[p], r, g, b);
+                        if (idx[p] != -1) {
+                            // Kernels with the dominant-axis shadow filter evaluate the ray direction again
+                            // here (same statements on the same table entries, hence the same bits) instead
+                            // of keeping it in registers across the shadow pass; the volatile reads keep the
+                            // compiler from merging the two evaluations.
+                            float rdx = dx[p], rdy = dy[p], rdz = dz[p];
+                            if (SHFAST)
+                                rc_ray_dir(a, *(volatile const float *)(a.sin_x + x), *(volatile const float *)(a.sin_y + row + a.y_offset),
+                                           rdx, rdy, rdz);
+                            rc_ext_shade(a, idx[p], minDist[p], rdx, rdy, rdz, (shadowed >> p) & 1u, r, g, b);
+                        }
                     } else if (idx[p] >= 0) {
                         rc_shade(a, idx[p], minDist[p], dx[p], dy[p], dz[p], r, g, b);
                     }
@@ -965,11 +1072,12 @@ __device__ __forceinline__ void rc_tiled_body(const RcKernArgs &a, char *lds)
 
 } // namespace
 
-template <int P, bool EXT, bool CULL, bool BINS = false>
+// SHFAST (EXT, brute-force shadows only): the shadow pass may use the dominant-axis form of its filter.
+template <int P, bool EXT, bool CULL, bool BINS = false, bool SHFAST = false>
 __global__ __launch_bounds__(256, (EXT && P == 4) ? 4 : 1) void rc_draw_tiled(RcKernArgs a)
 {
     extern __shared__ __attribute__((aligned(16))) char rc_lds[];
-    rc_tiled_body<P, EXT, CULL, BINS>(a, rc_lds);
+    rc_tiled_body<P, EXT, CULL, BINS, SHFAST>(a, rc_lds);
 }
 
 // Level 0 of the culled variant (caller workspace): one workgroup per bin of 4 x 4 workgroup tiles
@@ -1078,13 +1186,6 @@ __global__ __launch_bounds__(256) void rc_rgba8_kernel(const char *surface, size
 // Launchers (host)
 // ---------------------------------------------------------------------------------------
 
-// tuning switch for A/B runs: NAME=0 in the environment turns a default-on feature off
-static bool rc_env_off(const char *name)
-{
-    const char *v = getenv(name);
-    return v && v[0] == '0';
-}
-
 template <int P>
 static long long rc_tile_count(const RcKernArgs &a)
 {
@@ -1103,8 +1204,13 @@ static hipError_t rc_launch_tiled(RcKernArgs a, hipStream_t stream)
     if (a.cull && a.lds_cap > RC_CULL_CHUNK_MAX) a.lds_cap = RC_CULL_CHUNK_MAX;
     a.tiles_x = (a.width + 16 * P - 1) / (16 * P);
     a.tiles_y = (a.rows + 15) / 16;
-    static const bool exact_off = rc_env_off("RC_LDS_EXACT");     // read once
-    a.lds_exact = (!a.cull && a.lds_cap <= RC_LDS_EXACT_MAX && !exact_off) ? 1 : 0;
+    // The dominant-axis shadow filter pays from about a thousand spheres up (its set-up costs one barrier
+    // and a second evaluation of the ray directions per pixel; measured on 1280x768 ... 7680x4320 frames:
+    // 9 % slower at 256 spheres, even at 512, 4-10 % faster from 1024).
+    const bool axis_wanted = (a.tuning & RC_KTUNE_SHADOW_AXIS_ON) ||
+                             (a.n >= RC_SHADOW_FAST_MIN && !(a.tuning & RC_KTUNE_SHADOW_AXIS_OFF));
+    a.shadow_fast = (a.ext_mode && a.shadows && !a.cull && axis_wanted) ? 1 : 0;
+    a.lds_exact = (!a.cull && a.lds_cap <= RC_LDS_EXACT_MAX && !(a.tuning & RC_KTUNE_NO_LDS_EXACT)) ? 1 : 0;
     const size_t lds_plain = a.lds_exact ? rc_lds_bytes_exact(a.lds_cap) : rc_lds_bytes(a.lds_cap);
     const unsigned grid = (unsigned)rc_tile_count<P>(a);
     if (a.cull && a.bins) {
@@ -1126,6 +1232,7 @@ static hipError_t rc_launch_tiled(RcKernArgs a, hipStream_t stream)
         if constexpr (P <= 4) {
             if (a.cull && a.bins) hipLaunchKernelGGL((rc_draw_tiled<P, true, true, true>), dim3(grid), dim3(256), rc_lds_bytes_cull(a.lds_cap, true), stream, a);
             else if (a.cull) hipLaunchKernelGGL((rc_draw_tiled<P, true, true>), dim3(grid), dim3(256), rc_lds_bytes_cull(a.lds_cap, false), stream, a);
+            else if (a.shadow_fast) hipLaunchKernelGGL((rc_draw_tiled<P, true, false, false, true>), dim3(grid), dim3(256), lds_plain, stream, a);
             else hipLaunchKernelGGL((rc_draw_tiled<P, true, false>), dim3(grid), dim3(256), lds_plain, stream, a);
         } else {
             return hipErrorInvalidValue;           // EXT is built for <= 4 pixels per lane

@@ -26,6 +26,10 @@
 extern "C" {
 #endif
 
+/* Bumped whenever a struct layout, an enum value or the meaning of an argument changes; bindings compare
+ * it with rc_abi_version() of the library they loaded and refuse a mismatch. */
+#define RC_ABI_VERSION 2
+
 #define RC_OK 0
 #define RC_EINVAL (-100001)
 #define RC_ENOTBUILT (-100002)
@@ -77,6 +81,14 @@ enum {
                                 longer one test per (pixel, sphere) pair.                     */
 };
 
+/* rc_opts.tuning: overrides of launcher heuristics, for A/B measurements and for tests that must reach
+ * both sides of a heuristic on small scenes.  Every combination produces the same surfaces. */
+enum {
+    RC_TUNE_SHADOW_AXIS_ON = 1,   /* EXT: use the dominant-axis shadow filter whatever the sphere count  */
+    RC_TUNE_SHADOW_AXIS_OFF = 2,  /* EXT: never use it (default: from 1024 spheres up)                    */
+    RC_TUNE_NO_LDS_EXACT = 4      /* do not stage the exact-test terms in LDS beside the filter records  */
+};
+
 /* Shading modes. */
 enum {
     RC_MODE_REF = 0,   /* the reference's math: spheres, ambient + three directional Lambert
@@ -115,7 +127,7 @@ typedef struct rc_opts {
     void *rgba8;         /* optional DEVICE R8G8B8A8 surface written with the same frame   */
     size_t rgba8_pitch;  /* bytes per rgba8 row (>= 4*width)                               */
     int rgba8_flip;      /* != 0: surface row 0 goes to the LAST rgba8 row (top-down image)*/
-    int reserved1;
+    int tuning;          /* RC_TUNE_* bits; 0 = the library's own choices.  Never changes a pixel.  */
     const rc_ext *ext;   /* HOST pointer, required when mode == RC_MODE_EXT                */
     void *workspace;     /* optional DEVICE scratch, 16-byte aligned, rc_workspace_bytes(n) or more:
                             RC_VARIANT_CULLED then builds the sphere records once per frame in it
@@ -298,6 +310,8 @@ const rc_screen *rc_ctx_screen(const rc_ctx *ctx);
 const rc_scene *rc_ctx_scene(const rc_ctx *ctx);
 
 const char *rc_last_error_string(void);
+/* RC_ABI_VERSION the library was built with */
+int rc_abi_version(void);
 /* "rc_hip <version> gfx950" */
 const char *rc_version(void);
 

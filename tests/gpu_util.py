@@ -45,7 +45,7 @@ def to_rc_ext(ext):
 
 
 def gpu_render(pos, rad, col, cam, width, height, variant=abi.VARIANT_AUTO, y_offset=0, full_height=0,
-               pitch=None, want_rgba8=False, flip=False, fill=1, scene=None, ext=None, workspace=False):
+               pitch=None, want_rgba8=False, flip=False, fill=1, scene=None, ext=None, workspace=False, tuning=0):
     """Render through rc_render -> float32 [height, pitch/4] raw rows (and RGBA8 if asked)."""
     lib = abi.load()
     own = scene is None
@@ -54,7 +54,7 @@ def gpu_render(pos, rad, col, cam, width, height, variant=abi.VARIANT_AUTO, y_of
     surf = DeviceBuffer(pitch * height)
     abi.check(lib.rc_memset(surf.ptr, fill, pitch * height, None), "rc_memset")
     screen = abi.RcScreen(surf.ptr.value, width, height, pitch)
-    opts = abi.RcOpts(y_offset=y_offset, full_height=full_height, variant=variant)
+    opts = abi.RcOpts(y_offset=y_offset, full_height=full_height, variant=variant, tuning=tuning)
     if ext is not None:
         rc_ext = ext if isinstance(ext, abi.RcExt) else to_rc_ext(ext)
         opts.mode = abi.MODE_EXT

@@ -194,7 +194,9 @@ def test_filter_soak_tiled_vs_literal_on_device(oracle):
         if with_bins:
             got = pixels(gpu_render(pos, rad, col, cam, w, h, variant=abi.VARIANT_CULLED, scene=scene, workspace=True), w)
         else:
-            got = pixels(gpu_render(pos, rad, col, cam, w, h, variant=variants[it % 4], scene=scene), w)
+            # every other round of the four variants without the exact-test terms in LDS
+            got = pixels(gpu_render(pos, rad, col, cam, w, h, variant=variants[it % 4], scene=scene,
+                                    tuning=abi.TUNE_NO_LDS_EXACT if (it // 4) % 2 else 0), w)
         scene.free()
         assert_same_bits(got, want, f"soak {it}: n={n} cam={cpos} rot={rot} variant={variants[it % 4]}")
         if it % 5000 == 4999:
@@ -238,6 +240,9 @@ def test_ext_benchmark_frames_bit_exact(oracle, golden, name, variant):
     got = pixels(gpu_render(pos, rad, col, cam, w, h, variant=variant, ext=ext), w)
     assert_same_bits(got, want, name + " EXT")
     assert f"{oracle.fnv_words(got):016x}" == golden[name + "_ext"]["fnv"]
+    # the dominant-axis shadow filter (default only from 1024 spheres up) forced on
+    got = pixels(gpu_render(pos, rad, col, cam, w, h, variant=variant, ext=ext, tuning=abi.TUNE_SHADOW_AXIS_ON), w)
+    assert_same_bits(got, want, name + " EXT, dominant-axis shadow filter")
 
 
 @pytest.mark.parametrize("variant", EXT_VARIANTS)
@@ -258,6 +263,8 @@ def test_ext_option_matrix_and_odd_lights(oracle, variant):
         want = oracle.render(pos, rad, col, cam, w, h, ext=ext)
         got = pixels(gpu_render(pos, rad, col, cam, w, h, variant=variant, ext=ext), w)
         assert_same_bits(got, want, f"EXT {kw}")
+        got = pixels(gpu_render(pos, rad, col, cam, w, h, variant=variant, ext=ext, tuning=abi.TUNE_SHADOW_AXIS_ON), w)
+        assert_same_bits(got, want, f"EXT {kw}, dominant-axis shadow filter")
 
 
 def test_ext_random_scenes_stress(oracle):
@@ -273,8 +280,9 @@ def test_ext_random_scenes_stress(oracle):
                            plane_normal=tuple(float(v) for v in rng.normal(size=3)), plane_h=float(rng.uniform(-10, 10)))
         want = oracle.render(pos, rad, col, cam, w, h, ext=ext)
         variant = [abi.VARIANT_TILED2, abi.VARIANT_TILED4, abi.VARIANT_TILED][it % 3]
-        got = pixels(gpu_render(pos, rad, col, cam, w, h, variant=variant, ext=ext), w)
-        assert_same_bits(got, want, f"EXT stress {it}")
+        tuning = [0, abi.TUNE_SHADOW_AXIS_ON, abi.TUNE_SHADOW_AXIS_ON | abi.TUNE_NO_LDS_EXACT, abi.TUNE_NO_LDS_EXACT][it % 4]
+        got = pixels(gpu_render(pos, rad, col, cam, w, h, variant=variant, ext=ext, tuning=tuning), w)
+        assert_same_bits(got, want, f"EXT stress {it} tuning {tuning}")
 
 
 def test_ext_ragged_and_multichunk(oracle):
@@ -283,9 +291,10 @@ def test_ext_ragged_and_multichunk(oracle):
         cam = oracle.camera_data((0.5, -0.25, 21.0), (0.05, 0.1, 0.0), w, h)
         ext = _default_ext(oracle)
         want = oracle.render(pos, rad, col, cam, w, h, ext=ext)
-        for variant in (abi.VARIANT_AUTO, abi.VARIANT_CULLED):
-            got = pixels(gpu_render(pos, rad, col, cam, w, h, variant=variant, ext=ext), w)
-            assert_same_bits(got, want, f"EXT {w}x{h} n={n} variant {variant}")
+        for variant, tuning in ((abi.VARIANT_AUTO, 0), (abi.VARIANT_CULLED, 0), (abi.VARIANT_AUTO, abi.TUNE_SHADOW_AXIS_ON),
+                                (abi.VARIANT_AUTO, abi.TUNE_SHADOW_AXIS_OFF)):
+            got = pixels(gpu_render(pos, rad, col, cam, w, h, variant=variant, ext=ext, tuning=tuning), w)
+            assert_same_bits(got, want, f"EXT {w}x{h} n={n} variant {variant} tuning {tuning}")
 
 
 def test_ext_soak_tiled_vs_literal_on_device(oracle):
@@ -314,18 +323,32 @@ def test_ext_soak_tiled_vs_literal_on_device(oracle):
                            plane_h=float(rng.uniform(-spread, spread)), has_plane=int(rng.integers(2)))
         scene = GpuScene(pos, rad, col)
         want = pixels(gpu_render(pos, rad, col, cam, w, h, variant=abi.VARIANT_LITERAL, scene=scene, ext=ext), w)
-        got = pixels(gpu_render(pos, rad, col, cam, w, h, variant=variants[it % 3], scene=scene, ext=ext), w)
+        tuning = abi.TUNE_SHADOW_AXIS_ON if (it // 3) % 2 == 0 else 0     # both forms of the shadow filter
+        got = pixels(gpu_render(pos, rad, col, cam, w, h, variant=variants[it % 3], scene=scene, ext=ext, tuning=tuning), w)
         scene.free()
-        assert_same_bits(got, want, f"EXT soak {it}: n={n} cam={cpos} light={lpos} variant={variants[it % 3]}")
+        assert_same_bits(got, want, f"EXT soak {it}: n={n} cam={cpos} light={lpos} variant={variants[it % 3]} tuning={tuning}")
         if it % 5000 == 4999:
             print(f"EXT soak: {it + 1} scenes identical", flush=True)
 
 
+def test_tuning_bits_are_validated(rclib):
+    surf = DeviceBuffer(64 * 64 * 16)               # a real surface: a library that let the call through would only draw
+    screen = abi.RcScreen(surf.ptr.value, 64, 64, 1024)
+    scene = abi.RcScene()
+    assert rclib.rc_render(C.byref(screen), C.byref(scene), C.byref(abi.RcOpts(tuning=8))) == abi.RC_EINVAL
+    assert b"tuning" in rclib.rc_last_error_string()
+    abi.check(rclib.rc_sync(None))
+    surf.free()
+
+
 def test_ext_requires_parameters(rclib):
-    screen = abi.RcScreen(0x1000, 64, 64, 1024)
+    surf = DeviceBuffer(64 * 64 * 16)               # rejected calls never touch it; a real surface all the same
+    screen = abi.RcScreen(surf.ptr.value, 64, 64, 1024)
     scene = abi.RcScene()
     assert rclib.rc_render(C.byref(screen), C.byref(scene), C.byref(abi.RcOpts(mode=abi.MODE_EXT))) == abi.RC_EINVAL
     assert rclib.rc_render(C.byref(screen), C.byref(scene), C.byref(abi.RcOpts(mode=7))) == abi.RC_EINVAL
+    abi.check(rclib.rc_sync(None))
+    surf.free()
 
 
 def test_pitch_padding_untouched(oracle):
@@ -609,9 +632,12 @@ def test_sine_table_cache_eviction(oracle, rclib):
 
 def test_frame_size_limit(rclib):
     scene = abi.RcScene()
-    screen = abi.RcScreen(16, 65537, 4, 65537 * 16)
+    surf = DeviceBuffer(65537 * 16 * 4)
+    screen = abi.RcScreen(surf.ptr.value, 65537, 4, 65537 * 16)
     assert rclib.rc_render(C.byref(screen), C.byref(scene), None) == abi.RC_EINVAL
     assert b"65536" in rclib.rc_last_error_string()
+    abi.check(rclib.rc_sync(None))
+    surf.free()
     assert rclib.rc_prepare(70000, 4, 0.5) == abi.RC_EINVAL
 
 

@@ -87,14 +87,23 @@ def test_static_entry_row_band_and_rgba8(oracle, rclib):
 
 
 def test_static_entry_rejects_sizes_beyond_its_scratch(rclib):
+    """Every rejected call gets real device memory all the same: a library that wrongly accepted one would
+    draw into it instead of faulting the GPU."""
     scene = abi.RcScene()
-    screen = abi.RcScreen(16, 30000, 4000, 30000 * 16)            # 30000 + 4000 > 32768 table entries
-    assert rclib.rc_render_static(C.byref(screen), C.byref(scene), None) == abi.RC_EINVAL
+    surf = DeviceBuffer(30000 * 16 * 4)
+    screen = abi.RcScreen(surf.ptr.value, 30000, 4, 30000 * 16)
+    opts = abi.RcOpts(full_height=4000)                          # 30000 + 4000 > 32768 table entries
+    assert rclib.rc_render_static(C.byref(screen), C.byref(scene), C.byref(opts)) == abi.RC_EINVAL
     assert b"32768" in rclib.rc_last_error_string()
-    screen = abi.RcScreen(16, 64, 64, 1024)
+    screen = abi.RcScreen(surf.ptr.value, 64, 64, 1024)
     opts = abi.RcOpts(full_height=40000)
     assert rclib.rc_render_static(C.byref(screen), C.byref(scene), C.byref(opts)) == abi.RC_EINVAL
-    scene.sphere_num, scene.position, scene.radius, scene.color = 8193, 16, 16, 16
+    arrays = DeviceBuffer(8193 * 12)
+    scene.sphere_num = 8193
+    scene.position = scene.radius = scene.color = arrays.ptr.value
     opts = abi.RcOpts(variant=abi.VARIANT_CULLED)
     assert rclib.rc_render_static(C.byref(screen), C.byref(scene), C.byref(opts)) == abi.RC_EINVAL
     assert b"8192" in rclib.rc_last_error_string()
+    abi.check(rclib.rc_sync(None))
+    arrays.free()
+    surf.free()
