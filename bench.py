@@ -56,6 +56,9 @@ def parse():
     ap.add_argument("--gather", default="float", choices=["float", "rgba8"],
                     help="bands mode: what is gathered on rank 0 -- the float RGBA bands (16 B/pixel) or the fused "
                          "RGBA8 bands (4 B/pixel, a quarter of the xGMI traffic)")
+    ap.add_argument("--gather-impl", default="torch", choices=["torch", "c"],
+                    help="bands mode: torch = torch.distributed batch_isend_irecv on device tensors; c = librc_gather.so "
+                         "(grouped ncclSend/ncclRecv issued from C on its own stream; include/rc_gather.h)")
     ap.add_argument("--variant", default="tiled", choices=["tiled", "tiled2", "tiled4", "tiled8", "culled", "literal"])
     ap.add_argument("--shading", default="ref", choices=["ref", "ext"],
                     help="ref: the reference's math; ext: + plane, point light, Phong, hard shadows (unpinned by the reference)")
@@ -327,6 +330,14 @@ def main():
     sent = frame8 if gather8 else frame          # what the band gather moves
 
     gatherer = sharding.BandGather(h, world, rank, parts=args.subbands) if banded else None
+    cgather = None
+    if banded and args.gather_impl == "c":
+        if comm_device != "cuda":
+            raise SystemExit("--gather-impl c needs RCCL (it cannot run on the gloo rehearsal backend)")
+        from cudaraytracing_amd import gather as rcg
+        ident = [rcg.unique_id() if rank == 0 else None]
+        dist.broadcast_object_list(ident, src=0)          # carries the 128-byte identifier to every rank
+        cgather = rcg.Gather(world, rank, ident[0])
 
     def step(i):
         if args.sequence:
@@ -337,6 +348,23 @@ def main():
                 rc_ext.light_pos = abi.RcVec3(*configs.sequence_light(f))
         if gatherer is None:
             abi.check(lib.rc_render(C.byref(screen), C.byref(scene), C.byref(opts)), "rc_render")
+        elif cgather is not None:
+            # the same pieces, handed to librc_gather.so: each transfer runs on the library's stream behind
+            # an event on ours, so piece k travels while piece k + 1 renders
+            row_bytes = w * (4 if gather8 else 16)
+            for k in range(args.subbands):          # every rank makes the same calls; a band shorter than
+                sb, se = gatherer.pieces[k] if k < len(gatherer.pieces) else (y1, y1)   # `subbands` rows has empty pieces
+                if se > sb:
+                    piece = abi.RcScreen(frame[sb - y0:].data_ptr(), w, se - sb, w * 16)
+                    popts = abi.RcOpts.from_buffer_copy(bytes(opts))
+                    popts.ext = opts.ext
+                    popts.y_offset = sb
+                    if gather8:
+                        popts.rgba8 = frame8[sb - y0:].data_ptr()
+                    abi.check(lib.rc_render(C.byref(piece), C.byref(scene), C.byref(popts)), "rc_render")
+                cgather.piece(k, args.subbands, sent.data_ptr(), full.data_ptr() if full is not None else None,
+                              row_bytes, h, stream)
+            cgather.wait(stream)
         elif comm_device == "cuda":
             # render the band piece by piece; each piece is sent while the next one renders
             gatherer.post_receives(full)
@@ -607,7 +635,7 @@ def main():
             "vs_baseline": None, "dtype": "f32", "data": "synthetic",
             "config": {"workload": args.config, "width": w, "height": h, "spheres": n,
                        "mode": "REF" if args.shading == "ref" else "EXT (plane + point light + Phong + hard shadows; unpinned by the reference)",
-                       "variant": args.variant, "tuning": args.tuning, "sharding": args.mode, "gathered": (args.gather if banded else None), "backend": backend if world > 1 else None,
+                       "variant": args.variant, "tuning": args.tuning, "sharding": args.mode, "gathered": (args.gather if banded else None), "gather_impl": (args.gather_impl if banded else None), "backend": backend if world > 1 else None,
                        "camera": "sequence" if args.sequence else "static",
                        "device": name.value.decode(), "compute_units": cu.value, "clock_mhz": khz.value / 1e3},
             "frame_ms": kernel_ms, "frame_ms_stats": frame_stats, "per_rank_step_ms": per_rank_ms, "gather_check": gather_check,
@@ -658,6 +686,8 @@ def main():
         sys.stdout.flush()
         os.write(result_fd, (json.dumps(out) + "\n").encode())
 
+    if cgather is not None:
+        cgather.destroy()
     if use_dist:
         dist.destroy_process_group()
 

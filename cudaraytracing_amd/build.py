@@ -12,6 +12,8 @@ _ROOT = os.path.dirname(_HERE)
 CSRC = os.path.join(_HERE, "csrc")
 LIB_PATH = os.path.join(_HERE, "librc_hip.so")
 CLI_PATH = os.path.join(_HERE, "rc_render")
+GATHER_PATH = os.path.join(_HERE, "librc_gather.so")      # row-band assembly over RCCL (links librccl)
+GATHER_SRC = os.path.join(CSRC, "rc_gather.cpp")
 
 SOURCES = [os.path.join(CSRC, "rc_kernels.hip"), os.path.join(CSRC, "rc_host.hip")]
 HEADERS = [os.path.join(CSRC, "rc_kernels.h"), os.path.join(_ROOT, "include", "rc_abi.h")] + [
@@ -59,6 +61,22 @@ def build(force=False, verbose=False):
         finally:
             if os.path.exists(tmp):
                 os.remove(tmp)
+    gather_deps = [GATHER_SRC, os.path.join(_ROOT, "include", "rc_gather.h")]
+    if force or _stale(GATHER_PATH, gather_deps):
+        if os.path.exists(GATHER_PATH):
+            os.remove(GATHER_PATH)
+        rocm = os.path.dirname(os.path.dirname(os.path.realpath(hipcc_path())))
+        cmd = [hipcc_path(), "-O2", "-std=c++17", "-fPIC", "-Wall", "-x", "hip", "--offload-arch=gfx950",
+               "-I" + os.path.join(_ROOT, "include"), "-shared", "-o", GATHER_PATH + ".tmp", GATHER_SRC,
+               "-L" + os.path.join(rocm, "lib"), "-lrccl"]
+        if verbose:
+            print(" ".join(cmd))
+        try:
+            subprocess.run(cmd, check=True, cwd=_ROOT)
+            os.replace(GATHER_PATH + ".tmp", GATHER_PATH)
+        finally:
+            if os.path.exists(GATHER_PATH + ".tmp"):
+                os.remove(GATHER_PATH + ".tmp")
     cli_src = os.path.join(CSRC, "host", "rc_render_main.cpp")
     cli_deps = [cli_src, LIB_PATH] + [
         os.path.join(CSRC, "host", h) for h in ("rc_camera.hpp", "rc_scene_manager.hpp", "rc_raycaster.hpp", "rc_frame_pipeline.hpp")

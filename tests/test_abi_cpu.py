@@ -146,3 +146,31 @@ def test_header_is_plain_c99(tmp_path):
                     os.path.join(root, "examples", "render_frame.c"), "-L" + os.path.dirname(abi.LIB_PATH), "-lrc_hip",
                     "-Wl,-rpath," + os.path.dirname(abi.LIB_PATH), "-o", exe], check=True, capture_output=True)
     assert os.path.exists(exe)
+
+
+def test_gather_library_exports_every_declared_symbol():
+    """librc_gather.so (row-band assembly over RCCL): loads without a GPU, exports what include/rc_gather.h
+    declares, and its partition helpers agree with the Python ones the CPU sharding tests use."""
+    from cudaraytracing_amd import gather, sharding
+    text = open(os.path.join(ROOT, "include", "rc_gather.h")).read()
+    text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
+    declared = set(re.findall(r"\b(rc_[a-z0-9_]+)\s*\(", text))
+    assert declared == set(gather.SYMBOLS), declared ^ set(gather.SYMBOLS)
+    gather.load()
+    out = subprocess.run(["nm", "-D", "--defined-only", gather.LIB_PATH], capture_output=True, text=True, check=True).stdout
+    exported = {line.split()[-1] for line in out.splitlines() if line.strip()}
+    assert declared <= exported, declared - exported
+    assert "rccl" not in subprocess.run(["ldd", abi.LIB_PATH], capture_output=True, text=True).stdout   # only the gather library links RCCL
+    for h in (1, 7, 540, 1080, 4320):
+        for world in (1, 2, 3, 8):
+            for r in range(world):
+                b, e = configs.band_rows(h, world, r)
+                assert gather.band_rows(h, world, r) == (b, e)
+                for parts in (1, 2, 3, 5):
+                    py = sharding.sub_bands(b, e, parts)
+                    for k in range(parts):
+                        sb, se = gather.sub_band(b, e, parts, k)
+                        if k < len(py) and py[k][1] > py[k][0]:
+                            assert (sb, se) == py[k]
+                        else:
+                            assert sb == se

@@ -886,7 +886,8 @@ def test_bench_two_ranks_share_one_gpu(mode, extra, launcher):
         assert d["gather_check"] is True
 
 
-@pytest.mark.parametrize("extra", [[], ["--gather", "rgba8", "--subbands", "3"]])
+@pytest.mark.parametrize("extra", [[], ["--gather", "rgba8", "--subbands", "3"], ["--gather-impl", "c"],
+                                   ["--gather-impl", "c", "--gather", "rgba8", "--subbands", "3"]])
 def test_bench_band_assembly_on_device_tensors_one_rank(extra):
     """--mode bands on ONE rank still renders the band piece by piece (y_offset / full_height) and
     assembles the pieces on device tensors under a one-rank RCCL process group: the assembled frame
@@ -902,6 +903,37 @@ def test_bench_band_assembly_on_device_tensors_one_rank(extra):
     d = json.loads(lines[0])
     assert d["n_gpus"] == 1 and d["scaling"] == "strong" and d["gather_check"] is True
     assert d["config"]["sharding"] == "bands"
+
+
+def test_c_gather_one_rank_assembles_pieces(oracle):
+    """librc_gather.so with a one-rank communicator (ncclCommInitRank on this GPU): a band rendered in
+    three pieces, each handed to rc_gather_piece, arrives in the full frame bit for bit."""
+    from cudaraytracing_amd import gather
+    w, h, n = 320, 100, 40
+    pos, rad, col = oracle.generate_scene(n, 4)
+    cam = oracle.camera_data((0, 0, 20), (0, 0, 0), w, h)
+    lib = abi.load()
+    gs = GpuScene(pos, rad, col)
+    sc = gs.scene(cam)
+    band, full = DeviceBuffer(w * 16 * h), DeviceBuffer(w * 16 * h)
+    abi.check(lib.rc_memset(full.ptr, 0, w * 16 * h, None))
+    g = gather.Gather(1, 0, gather.unique_id())
+    parts = 3
+    for k in range(parts):
+        sb, se = gather.sub_band(0, h, parts, k)
+        screen = abi.RcScreen(band.ptr.value + sb * w * 16, w, se - sb, w * 16)
+        opts = abi.RcOpts(y_offset=sb, full_height=h)
+        abi.check(lib.rc_render(C.byref(screen), C.byref(sc), C.byref(opts)), "rc_render")
+        g.piece(k, parts, band.ptr, full.ptr, w * 16, h, None)
+    g.wait(None)
+    abi.check(lib.rc_sync(None))
+    got = np.empty((h, w, 4), np.float32)
+    abi.check(lib.rc_download_2d(got.ctypes.data_as(C.c_void_p), w * 16, full.ptr, w * 16, w * 16, h, None))
+    g.destroy()
+    for b in (band, full):
+        b.free()
+    gs.free()
+    assert_same_bits(got, oracle.render(pos, rad, col, cam, w, h), "frame assembled by librc_gather.so")
 
 
 def test_config4_split_eight_bands_two_pieces_each(oracle, golden):
