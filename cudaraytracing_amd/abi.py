@@ -9,7 +9,7 @@ import os
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "librc_hip.so")
 
-ABI_VERSION = 2     # RC_ABI_VERSION of include/rc_abi.h this binding was written against
+ABI_VERSION = 3     # RC_ABI_VERSION of include/rc_abi.h this binding was written against
 
 RC_OK = 0
 RC_EINVAL = -100001
@@ -66,6 +66,7 @@ class RcInput(C.Structure):
 TUNE_SHADOW_AXIS_ON = 1
 TUNE_SHADOW_AXIS_OFF = 2
 TUNE_NO_LDS_EXACT = 4
+TUNE_NO_NEAR_SKIP = 8
 
 MODE_REF = 0
 MODE_EXT = 1

@@ -29,7 +29,7 @@ static_assert(sizeof(rc_opts) == 72 && offsetof(rc_opts, stream) == 16 && offset
               offsetof(rc_opts, workspace) == 56, "rc_opts layout (mirrored by the ctypes binding)");
 static_assert(sizeof(rc_input) == 40, "rc_input layout");
 static_assert(RC_TUNE_SHADOW_AXIS_ON == RC_KTUNE_SHADOW_AXIS_ON && RC_TUNE_SHADOW_AXIS_OFF == RC_KTUNE_SHADOW_AXIS_OFF &&
-              RC_TUNE_NO_LDS_EXACT == RC_KTUNE_NO_LDS_EXACT, "tuning bits");
+              RC_TUNE_NO_LDS_EXACT == RC_KTUNE_NO_LDS_EXACT && RC_TUNE_NO_NEAR_SKIP == RC_KTUNE_NO_NEAR_SKIP, "tuning bits");
 static_assert(offsetof(rc_scene, position) == 8 && offsetof(rc_scene, radius) == 16 &&
               offsetof(rc_scene, color) == 24 && offsetof(rc_scene, cam) == 32, "Scene.h field offsets");
 static_assert(offsetof(rc_screen, width) == 8 && offsetof(rc_screen, height) == 12 &&
@@ -211,7 +211,8 @@ int rc_check_render_args(const rc_screen *screen, const rc_scene *scene, const r
         return rc_fail_arg("rgba8 surface must be 4-byte aligned with pitch >= 4*width, multiple of 4");
 
     if (o.mode != RC_MODE_REF && o.mode != RC_MODE_EXT) return rc_fail_arg("unknown mode");
-    if (o.tuning & ~(RC_TUNE_SHADOW_AXIS_ON | RC_TUNE_SHADOW_AXIS_OFF | RC_TUNE_NO_LDS_EXACT)) return rc_fail_arg("unknown tuning bits");
+    if (o.tuning & ~(RC_TUNE_SHADOW_AXIS_ON | RC_TUNE_SHADOW_AXIS_OFF | RC_TUNE_NO_LDS_EXACT | RC_TUNE_NO_NEAR_SKIP))
+        return rc_fail_arg("unknown tuning bits");
     if (o.mode == RC_MODE_EXT) {
         if (!o.ext) return rc_fail_arg("mode EXT needs opts->ext");
         if (o.ext->shininess_log2 < 0 || o.ext->shininess_log2 > 30) return rc_fail_arg("shininess_log2 must be 0..30");

@@ -10,7 +10,7 @@
 #define RC_LDS_EXACT_MAX 1024   // up to this chunk size the exact-test terms are staged too (+16 bytes each)
 
 // rc_opts.tuning bits as the launchers see them (same values as RC_TUNE_* in rc_abi.h)
-enum { RC_KTUNE_SHADOW_AXIS_ON = 1, RC_KTUNE_SHADOW_AXIS_OFF = 2, RC_KTUNE_NO_LDS_EXACT = 4 };
+enum { RC_KTUNE_SHADOW_AXIS_ON = 1, RC_KTUNE_SHADOW_AXIS_OFF = 2, RC_KTUNE_NO_LDS_EXACT = 4, RC_KTUNE_NO_NEAR_SKIP = 8 };
 enum { RC_KVARIANT_AUTO = 0, RC_KVARIANT_LITERAL = 1, RC_KVARIANT_TILED4 = 2, RC_KVARIANT_TILED2 = 3, RC_KVARIANT_TILED8 = 4 };
 
 // Passed by value as the kernel parameter, as the reference passes Screen and Scene
@@ -54,6 +54,7 @@ struct RcKernArgs {
     // filled in by the tiled launcher
     int lds_cap;             // spheres per LDS chunk (multiple of 32)
     int lds_exact;           // 1: the chunk's exact-test terms {2v, 4c} are staged in LDS as well
+    int near_skip;           // 1: exact tests are skipped for pixels already nearer than the sphere's near bound
     int shadow_fast;         // 1: launch the kernel whose EXT shadow pass may use the dominant-axis filter (set by the launcher)
     int tiles_x, tiles_y;    // workgroup tiles covering the surface
     int bins_x, bin_q, bin_stride; // bins per row, entries per list segment, bytes per bin

@@ -54,7 +54,31 @@ __device__ __forceinline__ void rc_ray_dir(const RcKernArgs &a, float sx, float 
 
 // Per-sphere terms of kernel.cu:53-58 that do not depend on the ray (all primary rays
 // share the origin): v = o - pos, 2v (exact), 4c (exact scaling of c = v.v - r*r).
-struct RcExactSphere { float tvx, tvy, tvz, c4; };
+struct RcExactSphere { float tvx, tvy, tvz, c4, near; };
+
+// Lower bound of every POSITIVE distance kernel.cu:52-67 can return for a sphere with v = o - pos,
+// vv = v.v and radius r, for any ray direction the reference normalises (|d| within 4.5u of 1,
+// u = 2^-24).  A pixel whose minDist is already <= this bound cannot be updated by the sphere
+// (kernel.cu:91 needs dist < minDist), so its exact test can be skipped without changing a bit.
+// Derivation, camera outside the sphere (c = vv - r^2 > 0): the first root t1 = B - sqrt(B^2 - c),
+// B = -(v.d), decreases in B, and B <= |v||d|, so in real numbers t1 >= |v| - r.  In the reference's
+// float evaluation B is off by <= 3u|v|, c by <= 5u vv, b^2 - 4c by <= u b^2 + u disc and |d|^2 by
+// <= 9u, which moves B^2 - c by at most 23u vv against r^2, i.e. the root by <= 11.5u vv/r, plus
+// <= 6u|v| for the roundings of -b - s, the halving and the 1e-6 offset:
+//      dist >= |v| - r - 11.5u vv/r - 6u|v| - 1.0001e-6 .
+// The bound below subtracts 32u vv/r + 64u|v| + 2e-6 instead, which also covers its own float
+// evaluation (hardware sqrt and reciprocal, <= 8u|v| in all).  When the first root comes out negative
+// the reference returns the second; then this bound is negative too and never skips anything
+// (minDist is always positive).  Spheres behind the camera return no positive distance while the bound
+// is positive: their larger root is <= -(|v| - r)/2, sixteen times the error bound away from zero.
+// Camera inside or at the sphere, r = 0, non-finite data: the bound is negative, -inf or NaN, and the
+// caller's test  minDist <= bound  is false.
+__device__ __forceinline__ float rc_near_bound(float vv, float r)
+{
+    const float L = __builtin_amdgcn_sqrtf(vv);
+    const float ar = fabsf(r);
+    return ((L - ar) - 0x1p-19f * (vv * __builtin_amdgcn_rcpf(ar))) - (0x1p-18f * L + 2.0e-6f);
+}
 
 __device__ __forceinline__ RcExactSphere rc_exact_sphere_from(const RcKernArgs &a, int i,
                                                              float ox, float oy, float oz)
@@ -62,10 +86,12 @@ __device__ __forceinline__ RcExactSphere rc_exact_sphere_from(const RcKernArgs &
     float px = a.position[3 * i + 0], py = a.position[3 * i + 1], pz = a.position[3 * i + 2];
     float r = a.radius[i];
     float vx = ox - px, vy = oy - py, vz = oz - pz;
-    float c = ((vx * vx + vy * vy) + vz * vz) - (r * r);
+    float vv = (vx * vx + vy * vy) + vz * vz;
+    float c = vv - (r * r);
     RcExactSphere e;
     e.tvx = 2.0f * vx; e.tvy = 2.0f * vy; e.tvz = 2.0f * vz;
     e.c4 = 4.0f * c;
+    e.near = rc_near_bound(vv, r);
     return e;
 }
 
@@ -335,6 +361,7 @@ __device__ __forceinline__ RcRecord rc_prepass_sphere(const RcKernArgs &a, int i
     if (exact) {                                            // the same statements as rc_exact_sphere_from
         exact->tvx = 2.0f * vx; exact->tvy = 2.0f * vy; exact->tvz = 2.0f * vz;
         exact->c4 = 4.0f * c;
+        exact->near = rc_near_bound(vv, r);
     }
     // hardware sqrt / reciprocal (1 ulp each) are enough here: the margins below absorb them
     float thr = __builtin_amdgcn_sqrtf(c) * (1.0f - 0x1p-19f) - 0x1p-17f * __builtin_amdgcn_sqrtf(vv);
@@ -368,7 +395,8 @@ __host__ __device__ constexpr size_t rc_lds_bytes(int cap) { return (size_t)cap 
 // The brute-force variant appends, when the chunk is small enough to keep the occupancy (lds_exact):
 //   float4 exact[cap]     {2v.x, 2v.y, 2v.z, 4c} of kernel.cu:53-58 per sphere, so that the exact re-test of
 //                         a flagged sphere reads one broadcast b128 instead of going back to global memory
-__host__ __device__ constexpr size_t rc_lds_bytes_exact(int cap) { return rc_lds_bytes(cap) + (size_t)cap * 16; }
+//   float  near[cap]      rc_near_bound of the sphere (-inf when the skip is switched off)
+__host__ __device__ constexpr size_t rc_lds_bytes_exact(int cap) { return rc_lds_bytes(cap) + (size_t)cap * 20; }
 // The culled variant appends: float wg_bounds[4][8] (per-wave tile bounds), ushort list[cap]
 // (indices of the spheres that pass the workgroup-tile test, one segment of cap/4 per wave),
 // int count[4] (entries per segment) and, with bin lists, int id[cap] (scene index of each slot's sphere).
@@ -382,7 +410,7 @@ __host__ __device__ constexpr size_t rc_lds_bytes_cull(int cap, bool with_ids)
 // are wave-uniform.
 template <int P>
 __device__ __forceinline__ void rc_visit_sphere(const RcKernArgs &a, const float *rec, const unsigned char *flagb,
-                                                const float4 *s_exact, int j, int sphere, bool lane_forced,
+                                                const float4 *s_exact, const float *s_near, int j, int sphere, bool lane_forced,
                                                 const float (&fa)[P], float fb, const float (&len)[P],
                                                 const float (&dx)[P], const float (&dy)[P], const float (&dz)[P],
                                                 float (&minDist)[P], int (&idx)[P])
@@ -390,11 +418,18 @@ __device__ __forceinline__ void rc_visit_sphere(const RcKernArgs &a, const float
     const float *g = rec + (j >> 2) * 12 + (j & 3);
     const float r = __builtin_fmaf(fb, g[4], g[0]);
     const float be = g[8];
-    const bool all = lane_forced || (flagb[j] != 0);
+    // pixels whose nearest hit so far is at or below the sphere's near bound cannot be updated by it
+    // (rc_near_bound); lanes with an out-of-range ray set-up are exempt, their d need not be a unit vector
+    float near_b = s_exact ? s_near[j] : -__builtin_inff();
+    const unsigned long long forced_lanes = __builtin_amdgcn_ballot_w64(lane_forced);
+    const unsigned long long all_mask = (flagb[j] != 0) ? ~0ull : forced_lanes;
     unsigned long long pm[P], any = 0ull;
 #pragma unroll
     for (int p = 0; p < P; p++) {
-        pm[p] = __builtin_amdgcn_ballot_w64(all || (__builtin_fmaf(fa[p], be, r) >= len[p]));
+        // wave masks combined on the scalar unit: no short-circuit evaluation, no divergent branches
+        const unsigned long long flag = __builtin_amdgcn_ballot_w64(__builtin_fmaf(fa[p], be, r) >= len[p]);
+        const unsigned long long far = __builtin_amdgcn_ballot_w64(minDist[p] <= near_b);
+        pm[p] = (flag | all_mask) & (~far | forced_lanes);
         any |= pm[p];
     }
     if (any == 0ull) return;
@@ -404,6 +439,11 @@ __device__ __forceinline__ void rc_visit_sphere(const RcKernArgs &a, const float
         e.tvx = v.x; e.tvy = v.y; e.tvz = v.z; e.c4 = v.w;
     } else {
         e = rc_exact_sphere(a, sphere);
+        if (a.near_skip) {
+            near_b = e.near;
+#pragma unroll
+            for (int p = 0; p < P; p++) pm[p] &= ~__builtin_amdgcn_ballot_w64(minDist[p] <= near_b) | forced_lanes;
+        }
     }
     // the exact test only for pixel columns in which some lane still flags the sphere
 #pragma unroll
@@ -448,6 +488,7 @@ __device__ __forceinline__ RcLightRecord rc_prepass_light(const RcKernArgs &a, i
     if (exact) {                                            // the same statements as rc_exact_sphere_from
         exact->tvx = 2.0f * vx; exact->tvy = 2.0f * vy; exact->tvz = 2.0f * vz;
         exact->c4 = 4.0f * c;
+        exact->near = 0.0f;                                 // not used by the shadow pass
     }
     float thr = __builtin_amdgcn_sqrtf(c) * (1.0f - 0x1p-19f) - 0x1p-17f * __builtin_amdgcn_sqrtf(vv);
     RcLightRecord rec;
@@ -681,7 +722,7 @@ __device__ __forceinline__ void rc_shadow_pass(const RcKernArgs &a, char *lds,
             unsigned char *flagb = reinterpret_cast<unsigned char *>(s_flag);
             for (int j = tid; j < cnb; j += kBlock) {
                 RcLightRecord r;
-                RcExactSphere ex = {0.0f, 0.0f, 0.0f, 0.0f};
+                RcExactSphere ex = {0.0f, 0.0f, 0.0f, 0.0f, 0.0f};
                 r.hx = 0.0f; r.hy = 0.0f; r.hz = 0.0f; r.always = false;
                 if (j < cn) r = rc_prepass_light(a, base + j, &ex);
                 if (fast_axis >= 0) {              // (s h_m, h_j, h_k) for the workgroup's dominant axis m
@@ -768,6 +809,7 @@ __device__ __forceinline__ void rc_tiled_body(const RcKernArgs &a, char *lds)
     unsigned *s_flag = reinterpret_cast<unsigned *>(lds + (size_t)cap * 12);
     int *s_has_always = reinterpret_cast<int *>(lds + (size_t)cap * 13);
     float4 *s_exact = (!CULL && a.lds_exact) ? reinterpret_cast<float4 *>(lds + rc_lds_bytes(cap)) : nullptr;
+    float *s_near = reinterpret_cast<float *>(lds + rc_lds_bytes(cap) + (size_t)cap * 16);   // valid with s_exact
 
     const int tid = threadIdx.x;
     const int wave = tid >> 6, lane = tid & 63;
@@ -926,14 +968,17 @@ __device__ __forceinline__ void rc_tiled_body(const RcKernArgs &a, char *lds)
                 unsigned char *flagb = reinterpret_cast<unsigned char *>(s_flag);
                 for (int j = tid; j < cnb; j += kBlock) {
                     RcRecord r;
-                    RcExactSphere ex = {0.0f, 0.0f, 0.0f, 0.0f};
+                    RcExactSphere ex = {0.0f, 0.0f, 0.0f, 0.0f, 0.0f};
                     r.alpha = kNever; r.gamma = 0.0f; r.beta = 0.0f; r.always = false;
                     if (j < cn) r = rc_prepass_sphere(a, base + j, &ex);
                     float *g = rec + (j >> 2) * 12 + (j & 3);
                     g[0] = r.alpha; g[4] = r.gamma; g[8] = r.beta;
                     flagb[j] = r.always ? 1 : 0;
                     if (r.always) atomicOr(s_has_always, 1);
-                    if (s_exact) s_exact[j] = make_float4(ex.tvx, ex.tvy, ex.tvz, ex.c4);
+                    if (s_exact) {
+                        s_exact[j] = make_float4(ex.tvx, ex.tvy, ex.tvz, ex.c4);
+                        s_near[j] = (a.near_skip && !r.always && j < cn) ? ex.near : -__builtin_inff();
+                    }
                 }
                 __syncthreads();
             }
@@ -966,7 +1011,7 @@ __device__ __forceinline__ void rc_tiled_body(const RcKernArgs &a, char *lds)
                             const int bit = __builtin_ctzll(cand_mask);
                             cand_mask &= cand_mask - 1ull;
                             const int j = __builtin_amdgcn_readlane(jl, bit);
-                            rc_visit_sphere<P>(a, rec, flagb, nullptr, j, BINS ? s_id[j] : base + j, lane_forced, fa, fb, len,
+                            rc_visit_sphere<P>(a, rec, flagb, nullptr, nullptr, j, BINS ? s_id[j] : base + j, lane_forced, fa, fb, len,
                                                dx, dy, dz, minDist, idx);
                         }
                     }
@@ -1017,7 +1062,7 @@ __device__ __forceinline__ void rc_tiled_body(const RcKernArgs &a, char *lds)
                     while (cand_mask != 0ull) {
                         const int bit = __builtin_ctzll(cand_mask);
                         cand_mask &= cand_mask - 1ull;
-                        rc_visit_sphere<P>(a, rec, flagb, s_exact, blk * kBlockSpheres + bit, base + blk * kBlockSpheres + bit, lane_forced, fa, fb, len,
+                        rc_visit_sphere<P>(a, rec, flagb, s_exact, s_near, blk * kBlockSpheres + bit, base + blk * kBlockSpheres + bit, lane_forced, fa, fb, len,
                                            dx, dy, dz, minDist, idx);
                     }
                 }
@@ -1074,7 +1119,7 @@ __device__ __forceinline__ void rc_tiled_body(const RcKernArgs &a, char *lds)
 
 // SHFAST (EXT, brute-force shadows only): the shadow pass may use the dominant-axis form of its filter.
 template <int P, bool EXT, bool CULL, bool BINS = false, bool SHFAST = false>
-__global__ __launch_bounds__(256, (EXT && P == 4) ? 4 : 1) void rc_draw_tiled(RcKernArgs a)
+__global__ __launch_bounds__(256, ((EXT && P == 4) || P == 8) ? 4 : 1) void rc_draw_tiled(RcKernArgs a)
 {
     extern __shared__ __attribute__((aligned(16))) char rc_lds[];
     rc_tiled_body<P, EXT, CULL, BINS, SHFAST>(a, rc_lds);
@@ -1211,6 +1256,7 @@ static hipError_t rc_launch_tiled(RcKernArgs a, hipStream_t stream)
                              (a.n >= RC_SHADOW_FAST_MIN && !(a.tuning & RC_KTUNE_SHADOW_AXIS_OFF));
     a.shadow_fast = (a.ext_mode && a.shadows && !a.cull && axis_wanted) ? 1 : 0;
     a.lds_exact = (!a.cull && a.lds_cap <= RC_LDS_EXACT_MAX && !(a.tuning & RC_KTUNE_NO_LDS_EXACT)) ? 1 : 0;
+    a.near_skip = (a.tuning & RC_KTUNE_NO_NEAR_SKIP) ? 0 : 1;
     const size_t lds_plain = a.lds_exact ? rc_lds_bytes_exact(a.lds_cap) : rc_lds_bytes(a.lds_cap);
     const unsigned grid = (unsigned)rc_tile_count<P>(a);
     if (a.cull && a.bins) {

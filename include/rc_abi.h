@@ -28,7 +28,7 @@ extern "C" {
 
 /* Bumped whenever a struct layout, an enum value or the meaning of an argument changes; bindings compare
  * it with rc_abi_version() of the library they loaded and refuse a mismatch. */
-#define RC_ABI_VERSION 2
+#define RC_ABI_VERSION 3
 
 #define RC_OK 0
 #define RC_EINVAL (-100001)
@@ -86,7 +86,9 @@ enum {
 enum {
     RC_TUNE_SHADOW_AXIS_ON = 1,   /* EXT: use the dominant-axis shadow filter whatever the sphere count  */
     RC_TUNE_SHADOW_AXIS_OFF = 2,  /* EXT: never use it (default: from 1024 spheres up)                    */
-    RC_TUNE_NO_LDS_EXACT = 4      /* do not stage the exact-test terms in LDS beside the filter records  */
+    RC_TUNE_NO_LDS_EXACT = 4,     /* do not stage the exact-test terms in LDS beside the filter records  */
+    RC_TUNE_NO_NEAR_SKIP = 8      /* run the exact test also for pixels whose nearest hit so far is already
+                                     closer than the sphere's nearest point                               */
 };
 
 /* Shading modes. */

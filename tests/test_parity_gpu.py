@@ -194,13 +194,43 @@ def test_filter_soak_tiled_vs_literal_on_device(oracle):
         if with_bins:
             got = pixels(gpu_render(pos, rad, col, cam, w, h, variant=abi.VARIANT_CULLED, scene=scene, workspace=True), w)
         else:
-            # every other round of the four variants without the exact-test terms in LDS
+            # rounds of the four variants alternate the exact-test staging and the near-bound skip
             got = pixels(gpu_render(pos, rad, col, cam, w, h, variant=variants[it % 4], scene=scene,
-                                    tuning=abi.TUNE_NO_LDS_EXACT if (it // 4) % 2 else 0), w)
+                                    tuning=[0, abi.TUNE_NO_LDS_EXACT, abi.TUNE_NO_NEAR_SKIP, abi.TUNE_NO_LDS_EXACT | abi.TUNE_NO_NEAR_SKIP][(it // 4) % 4]), w)
         scene.free()
         assert_same_bits(got, want, f"soak {it}: n={n} cam={cpos} rot={rot} variant={variants[it % 4]}")
         if it % 5000 == 4999:
             print(f"soak: {it + 1} scenes identical", flush=True)      # progress for long runs (pytest -s)
+
+
+@pytest.mark.parametrize("variant", [abi.VARIANT_TILED2, abi.VARIANT_TILED8, abi.VARIANT_CULLED])
+def test_near_bound_skip_depth_ties(oracle, variant):
+    """The exact test is skipped for pixels already nearer than a sphere's nearest point.  Scenes built to
+    sit on that decision: every sphere's nearest point lies at (almost) the same distance D0 from the
+    camera -- offsets from 0 to 1e-3 relative -- with radii of 1e-3 ... 0.3 D0, stacked along a few shared
+    directions, so around each shared centre pixel the nearest hit so far and the next sphere's bound differ
+    by rounding errors only; duplicated spheres add exact ties.  (A bound raised by 2^-16 |v| fails this test.)"""
+    rng = np.random.default_rng(2024)
+    w, h = 192, 128
+    for it in range(12):
+        n = int(rng.integers(40, 400))
+        d0 = float(10.0 ** rng.uniform(0.0, 2.5))
+        # a handful of directions, several spheres stacked along each: around the shared centre pixel their
+        # hit distances differ by the offsets alone
+        ang = rng.uniform(-0.3, 0.3, (max(n // 8, 1), 2))[rng.integers(0, max(n // 8, 1), n)]
+        dirs = np.stack([np.sin(ang[:, 0]), np.sin(ang[:, 1]), -np.ones(n)], axis=1)
+        dirs /= np.linalg.norm(dirs, axis=1, keepdims=True)
+        rad = (d0 * 10.0 ** rng.uniform(-3, -0.5, n)).astype(np.float32)
+        off = rng.choice([0.0, 1e-7, -1e-7, 3e-7, -3e-7, 1e-6, -1e-6, 3e-6, -3e-6, 1e-5, -1e-5, 1e-4, -1e-4, 1e-3], n) * d0
+        pos = (dirs * (d0 + rad.astype(np.float64) + off)[:, None]).astype(np.float32)
+        pos[1::7] = pos[0::7][: len(pos[1::7])]          # exact duplicates: the lowest index must win
+        rad[1::7] = rad[0::7][: len(rad[1::7])]
+        col = rng.uniform(0, 1, (n, 3)).astype(np.float32)
+        cam = oracle.camera_data((0.0, 0.0, 0.0), (0.0, 0.0, 0.0), w, h)
+        want = oracle.render(pos, rad, col, cam, w, h)
+        got = pixels(gpu_render(pos, rad, col, cam, w, h, variant=variant, workspace=(variant == abi.VARIANT_CULLED and it % 2 == 0)), w)
+        assert_same_bits(got, want, f"depth ties {it}: n={n} d0={d0}")
+        assert int(want[..., :3].any(axis=2).sum()) > 1000
 
 
 @pytest.mark.parametrize("scale", [1e-12, 1e-6, 1e-3, 1e3, 1e6, 1e12, 1e18])
@@ -335,7 +365,7 @@ def test_tuning_bits_are_validated(rclib):
     surf = DeviceBuffer(64 * 64 * 16)               # a real surface: a library that let the call through would only draw
     screen = abi.RcScreen(surf.ptr.value, 64, 64, 1024)
     scene = abi.RcScene()
-    assert rclib.rc_render(C.byref(screen), C.byref(scene), C.byref(abi.RcOpts(tuning=8))) == abi.RC_EINVAL
+    assert rclib.rc_render(C.byref(screen), C.byref(scene), C.byref(abi.RcOpts(tuning=16))) == abi.RC_EINVAL
     assert b"tuning" in rclib.rc_last_error_string()
     abi.check(rclib.rc_sync(None))
     surf.free()
