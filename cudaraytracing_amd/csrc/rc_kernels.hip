@@ -60,19 +60,22 @@ struct RcExactSphere { float tvx, tvy, tvz, c4, near; };
 // vv = v.v and radius r, for any ray direction the reference normalises (|d| within 4.5u of 1,
 // u = 2^-24).  A pixel whose minDist is already <= this bound cannot be updated by the sphere
 // (kernel.cu:91 needs dist < minDist), so its exact test can be skipped without changing a bit.
-// Derivation, camera outside the sphere (c = vv - r^2 > 0): the first root t1 = B - sqrt(B^2 - c),
-// B = -(v.d), decreases in B, and B <= |v||d|, so in real numbers t1 >= |v| - r.  In the reference's
-// float evaluation B is off by <= 3u|v|, c by <= 5u vv, b^2 - 4c by <= u b^2 + u disc and |d|^2 by
-// <= 9u, which moves B^2 - c by at most 23u vv against r^2, i.e. the root by <= 11.5u vv/r, plus
-// <= 6u|v| for the roundings of -b - s, the halving and the 1e-6 offset:
-//      dist >= |v| - r - 11.5u vv/r - 6u|v| - 1.0001e-6 .
+// Derivation, camera outside the sphere (c = vv - r^2 > 0).  In real numbers the first root
+// t1 = B - sqrt(B^2 - c), B = -(v.d), decreases in B and B <= |v||d|, so t1 >= |v| - r.  In the
+// reference's float evaluation (gamma_3 bounds for the three-term dot products):
+//   B~ = -b/2 is within 3.01u |v||d| of B, hence B~ <= |v|(1 + 7.6u);
+//   c~ is within 5.1u vv of c;  disc~/4 = (B~^2 (1 + d1) - c~)(1 + d2);  s~ = sqrt(disc~)(1 + d3);
+//   so (s~/2)^2 <= B~^2 - C' with C' >= c - 9.2u vv, and  B~ - s~/2 >= g(B~) = B~ - sqrt(B~^2 - C') >= g(|v|(1 + 7.6u));
+//   there B~^2 - C' <= r^2 + 24.5u vv, whose root is <= r + 12.25u vv/r;
+//   the roundings of -b - s, the exact halving and the subtraction of 1e-6f cost another 2.01u |v|:
+//      dist >= |v| - r - 12.25u vv/r - 2.01u|v| - 1.0000001e-6 .
 // The bound below subtracts 32u vv/r + 64u|v| + 2e-6 instead, which also covers its own float
-// evaluation (hardware sqrt and reciprocal, <= 8u|v| in all).  When the first root comes out negative
-// the reference returns the second; then this bound is negative too and never skips anything
-// (minDist is always positive).  Spheres behind the camera return no positive distance while the bound
-// is positive: their larger root is <= -(|v| - r)/2, sixteen times the error bound away from zero.
-// Camera inside or at the sphere, r = 0, non-finite data: the bound is negative, -inf or NaN, and the
-// caller's test  minDist <= bound  is false.
+// evaluation (hardware sqrt and reciprocal: it can overestimate |v| - r by <= 7u|v|).  When the first
+// root comes out negative the reference returns the second; then this bound is negative too and never
+// skips anything (minDist is always positive).  Spheres behind the camera return no positive distance
+// while the bound is positive: their larger root is <= -(|v| - r)/2, more than sixteen times the error
+// bound away from zero.  Camera inside or at the sphere, r = 0, overflow, non-finite data: the bound is
+// negative, -inf or NaN, and the caller's test  minDist <= bound  is false.
 __device__ __forceinline__ float rc_near_bound(float vv, float r)
 {
     const float L = __builtin_amdgcn_sqrtf(vv);
