@@ -1246,6 +1246,12 @@ static hipError_t rc_launch_tiled(RcKernArgs a, hipStream_t stream)
     // LDS chunk: the whole scene when it fits (rounded up to whole blocks of kBlockSpheres)
     const int n16 = ((a.n > 0 ? a.n : 1) + kBlockSpheres - 1) & ~(kBlockSpheres - 1);
     a.lds_cap = n16 < RC_LDS_CHUNK_MAX ? n16 : RC_LDS_CHUNK_MAX;
+    // Above 2048 spheres a whole-scene chunk (13 bytes per sphere, 53 KB at 4096) leaves room for three
+    // workgroups per CU only: passes of 1024 spheres keep four resident and let the exact-test terms ride
+    // along in LDS.  Measured, REF: 7680x4320 x 4096 4.25 vs 4.43 ms, a 7680x540 band 0.684 vs 0.711 ms,
+    // 1280x768 x 4096 0.228 vs 0.257 ms, neutral at 2048 spheres.  EXT gains only on frames with many
+    // workgroups (3840x2160 x 4096: 2.67 vs 2.85 ms; 1920x1080 x 4096: 1.03 vs 0.97 ms).
+    if (a.n > 2048 && !a.cull && (!a.ext_mode || rc_tile_count<P>(a) >= 4096)) a.lds_cap = RC_LDS_EXACT_MAX;
     // The culled variant is latency-bound while it builds its records, so it wants many
     // resident workgroups: 1024-sphere passes (17 KB of LDS) measured 1.5x faster at
     // 7680x4320 x 4096 spheres than one 4096-sphere pass (62 KB, two workgroups per CU).
