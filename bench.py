@@ -56,6 +56,10 @@ def parse():
     ap.add_argument("--gather", default="float", choices=["float", "rgba8"],
                     help="bands mode: what is gathered on rank 0 -- the float RGBA bands (16 B/pixel) or the fused "
                          "RGBA8 bands (4 B/pixel, a quarter of the xGMI traffic)")
+    ap.add_argument("--band-layout", default="contiguous", choices=["contiguous", "interleaved"],
+                    help="bands mode: contiguous = rank r renders rows [r H/N, (r+1) H/N) in `subbands` pieces; interleaved = the "
+                         "frame is cut into 2N bands and rank r renders band r and band N+r (an outer band with an "
+                         "inner one: evens out the hit-heavy middle of the picture)")
     ap.add_argument("--gather-impl", default="torch", choices=["torch", "c"],
                     help="bands mode: torch = torch.distributed batch_isend_irecv on device tensors; c = librc_gather.so "
                          "(grouped ncclSend/ncclRecv issued from C on its own stream; include/rc_gather.h)")
@@ -302,12 +306,15 @@ def main():
     cam.position, cam.rotation = cfg["position"], cfg["rotation"]
     scene.cam = cam.get_data()
 
-    if args.mode == "bands":
-        y0, y1 = configs.band_rows(h, world, rank)
-    else:
-        y0, y1 = 0, h
-    rows = y1 - y0
-    # the frame lives in a torch tensor so that the band gather can use torch.distributed
+    banded = args.mode == "bands"      # also with one rank: the rows are still rendered piece by piece
+                                       # with y_offset and assembled into `full` by the same code
+    gatherer = sharding.BandGather(h, world, rank, parts=args.subbands, layout=args.band_layout) if banded else None
+    if banded and args.gather_impl == "c" and args.band_layout != "contiguous":
+        raise SystemExit("--gather-impl c assembles contiguous bands only")
+    y0 = gatherer.pieces[0][0] if banded else 0
+    rows = gatherer.rows if banded else h
+    # the frame lives in a torch tensor so that the band gather can use torch.distributed; in bands mode
+    # it holds this rank's pieces one after the other
     frame = torch.empty((rows, w, 4), dtype=torch.float32, device="cuda")
     screen = abi.RcScreen(frame.data_ptr(), w, rows, w * 16)
     stream = torch.cuda.current_stream().cuda_stream
@@ -318,8 +325,6 @@ def main():
         opts.mode = abi.MODE_EXT
         opts.ext = C.pointer(rc_ext)
     full = None
-    banded = args.mode == "bands"      # also with one rank: the band is still rendered piece by piece
-                                       # with y_offset and assembled into `full` by the same code
     gather8 = banded and args.gather == "rgba8"
     frame8 = torch.empty((rows, w), dtype=torch.int32, device="cuda") if gather8 else None
     if gather8:           # the draw kernel writes the display surface too; that one travels
@@ -329,7 +334,6 @@ def main():
                 else torch.empty((h, w, 4), dtype=torch.float32, device="cuda"))
     sent = frame8 if gather8 else frame          # what the band gather moves
 
-    gatherer = sharding.BandGather(h, world, rank, parts=args.subbands) if banded else None
     cgather = None
     if banded and args.gather_impl == "c":
         if comm_device != "cuda":
@@ -338,6 +342,20 @@ def main():
         ident = [rcg.unique_id() if rank == 0 else None]
         dist.broadcast_object_list(ident, src=0)          # carries the 128-byte identifier to every rank
         cgather = rcg.Gather(world, rank, ident[0])
+
+    def render_piece(k):
+        """Piece k of this rank's rows into its place in `frame` (rc_opts.y_offset = its first frame row)."""
+        sb, se = gatherer.pieces[k]
+        if se <= sb:
+            return
+        o = gatherer.offsets[k]
+        piece = abi.RcScreen(frame[o:].data_ptr(), w, se - sb, w * 16)
+        popts = abi.RcOpts.from_buffer_copy(bytes(opts))
+        popts.ext = opts.ext
+        popts.y_offset = sb
+        if gather8:
+            popts.rgba8 = frame8[o:].data_ptr()
+        abi.check(lib.rc_render(C.byref(piece), C.byref(scene), C.byref(popts)), "rc_render")
 
     def step(i):
         if args.sequence:
@@ -349,41 +367,33 @@ def main():
         if gatherer is None:
             abi.check(lib.rc_render(C.byref(screen), C.byref(scene), C.byref(opts)), "rc_render")
         elif cgather is not None:
-            # the same pieces, handed to librc_gather.so: each transfer runs on the library's stream behind
-            # an event on ours, so piece k travels while piece k + 1 renders
+            # the pieces handed to librc_gather.so: each transfer runs on the library's stream behind an
+            # event on ours, so piece k travels while piece k + 1 renders.  Every rank makes the same calls;
+            # a band shorter than `subbands` rows has empty pieces.
             row_bytes = w * (4 if gather8 else 16)
-            for k in range(args.subbands):          # every rank makes the same calls; a band shorter than
-                sb, se = gatherer.pieces[k] if k < len(gatherer.pieces) else (y1, y1)   # `subbands` rows has empty pieces
-                if se > sb:
-                    piece = abi.RcScreen(frame[sb - y0:].data_ptr(), w, se - sb, w * 16)
-                    popts = abi.RcOpts.from_buffer_copy(bytes(opts))
-                    popts.ext = opts.ext
-                    popts.y_offset = sb
-                    if gather8:
-                        popts.rgba8 = frame8[sb - y0:].data_ptr()
-                    abi.check(lib.rc_render(C.byref(piece), C.byref(scene), C.byref(popts)), "rc_render")
+            for k in range(args.subbands):
+                if k < len(gatherer.pieces):
+                    render_piece(k)
                 cgather.piece(k, args.subbands, sent.data_ptr(), full.data_ptr() if full is not None else None,
                               row_bytes, h, stream)
             cgather.wait(stream)
         elif comm_device == "cuda":
-            # render the band piece by piece; each piece is sent while the next one renders
+            # render piece by piece; each piece is sent while the next one renders
             gatherer.post_receives(full)
-            for k, (sb, se) in enumerate(gatherer.pieces):
-                if se > sb:
-                    piece = abi.RcScreen(frame[sb - y0:].data_ptr(), w, se - sb, w * 16)
-                    popts = abi.RcOpts.from_buffer_copy(bytes(opts))
-                    popts.ext = opts.ext
-                    popts.y_offset = sb
-                    if gather8:
-                        popts.rgba8 = frame8[sb - y0:].data_ptr()
-                    abi.check(lib.rc_render(C.byref(piece), C.byref(scene), C.byref(popts)), "rc_render")
+            for k in range(len(gatherer.pieces)):
+                render_piece(k)
                 gatherer.piece_rendered(k, sent, full)
             gatherer.wait()
-        else:                                   # rehearsal backend: stage through host memory
-            abi.check(lib.rc_render(C.byref(screen), C.byref(scene), C.byref(opts)), "rc_render")
+        else:                                   # rehearsal backend: the same exchange staged through host memory
+            for k in range(len(gatherer.pieces)):
+                render_piece(k)
             torch.cuda.current_stream().synchronize()
+            host_band = sent.cpu()
             host_full = torch.empty(full.shape, dtype=full.dtype) if rank == 0 else None
-            sharding.gather_bands(sent.cpu(), host_full, h, world, rank, dst=0)
+            gatherer.post_receives(host_full)
+            for k in range(len(gatherer.pieces)):
+                gatherer.piece_rendered(k, host_band, host_full)
+            gatherer.wait()
             if rank == 0:
                 full.copy_(host_full)
 
@@ -635,7 +645,8 @@ def main():
             "vs_baseline": None, "dtype": "f32", "data": "synthetic",
             "config": {"workload": args.config, "width": w, "height": h, "spheres": n,
                        "mode": "REF" if args.shading == "ref" else "EXT (plane + point light + Phong + hard shadows; unpinned by the reference)",
-                       "variant": args.variant, "tuning": args.tuning, "sharding": args.mode, "gathered": (args.gather if banded else None), "gather_impl": (args.gather_impl if banded else None), "backend": backend if world > 1 else None,
+                       "variant": args.variant, "tuning": args.tuning, "sharding": args.mode, "gathered": (args.gather if banded else None), "gather_impl": (args.gather_impl if banded else None),
+                       "band_layout": (args.band_layout if banded else None), "backend": backend if world > 1 else None,
                        "camera": "sequence" if args.sequence else "static",
                        "device": name.value.decode(), "compute_units": cu.value, "clock_mhz": khz.value / 1e3},
             "frame_ms": kernel_ms, "frame_ms_stats": frame_stats, "per_rank_step_ms": per_rank_ms, "gather_check": gather_check,

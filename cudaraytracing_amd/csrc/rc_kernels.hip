@@ -1319,7 +1319,11 @@ hipError_t rc_launch_draw(const RcKernArgs &a, int variant, int compute_units, h
     // EXT keeps shadow-ray state per pixel: at most 4 pixels per lane.  The culled variant
     // prefers small wave tiles (fewer pixels share a visited sphere): 4 at most as well.
     if (!a.ext_mode && !a.cull && rc_tile_count<8>(a) >= want) return rc_launch_tiled<8>(a, stream);
-    if (rc_tile_count<4>(a) >= want) return rc_launch_tiled<4>(a, stream);
+    // EXT below 2048 spheres: 4 pixels per lane pay only from 10 workgroups per CU (tools/p_sweep.py, 1920x1080:
+    // 2 pixels per lane 2 % faster at 64 spheres, 6 % at 256, 5 % at 1024, but 5 % slower at 4096; at
+    // 2560x1440 4 pixels per lane win at every count).
+    const long long want4 = (a.ext_mode && !a.cull && a.n < 2048) ? 2 * want : want;
+    if (rc_tile_count<4>(a) >= want4) return rc_launch_tiled<4>(a, stream);
     return rc_launch_tiled<2>(a, stream);
 }
 

@@ -63,19 +63,42 @@ def sub_bands(begin, end, parts):
     return out
 
 
+def rank_pieces(height, world, rank, parts=2, layout="contiguous"):
+    """Row ranges [(begin, end), ...] that `rank` renders, in the order it renders and sends them.
+
+    contiguous  one band per rank (configs.band_rows), cut into `parts` sub-bands.
+    interleaved the frame is cut into 2 * world bands and rank r takes band r and band world + r: rows near
+                the middle of the picture cost more than rows near its edges (more hits), and with a cost
+                that is symmetric about the middle this pairs band r with the mirror image of band
+                world - 1 - r, an outer band with an inner one.  Always two pieces.
+    """
+    if layout == "contiguous":
+        return sub_bands(*band_rows(height, world, rank), parts)
+    if layout == "interleaved":
+        return [band_rows(height, 2 * world, rank), band_rows(height, 2 * world, world + rank)]
+    raise ValueError(f"unknown band layout {layout!r}")
+
+
 class BandGather:
     """Row-band gather with render/transfer overlap.
 
-    A rank's band is rendered in `parts` sub-bands; the transfer of sub-band k is posted as soon
-    as its render has been enqueued, so it travels while sub-band k+1 renders (the collective
+    A rank's rows are rendered piece by piece (rank_pieces); the transfer of piece k is posted as soon
+    as its render has been enqueued, so it travels while piece k+1 renders (the collective
     library orders each transfer after the work already enqueued on the current stream).  The
-    root posts all its receives first, straight into the rows of the full frame.
+    root posts all its receives first, straight into the rows of the full frame.  A rank keeps its
+    pieces one after the other in one [rows, width, ...] tensor.
     """
 
-    def __init__(self, height, world, rank, parts=2, dst=0):
-        self.height, self.world, self.rank, self.parts, self.dst = height, world, rank, parts, dst
-        self.begin, self.end = band_rows(height, world, rank)
-        self.pieces = sub_bands(self.begin, self.end, parts)
+    def __init__(self, height, world, rank, parts=2, dst=0, layout="contiguous"):
+        self.height, self.world, self.rank, self.dst, self.layout = height, world, rank, dst, layout
+        self.parts = 2 if layout == "interleaved" else parts
+        self.begin, self.end = band_rows(height, world, rank)      # the contiguous band (layout "contiguous")
+        self.pieces = rank_pieces(height, world, rank, parts, layout)
+        self.offsets, o = [], 0                                    # first row of piece k inside this rank's tensor
+        for b, e in self.pieces:
+            self.offsets.append(o)
+            o += e - b
+        self.rows = o
         self._reqs = []
 
     def post_receives(self, full):
@@ -88,8 +111,7 @@ class BandGather:
             for r in range(self.world):
                 if r == self.dst:
                     continue
-                b, e = band_rows(self.height, self.world, r)
-                pieces = sub_bands(b, e, self.parts)
+                pieces = rank_pieces(self.height, self.world, r, self.parts, self.layout)
                 if k < len(pieces) and pieces[k][1] > pieces[k][0]:
                     ops.append(dist.P2POp(dist.irecv, full[pieces[k][0]:pieces[k][1]], r))
             if ops:
@@ -101,7 +123,7 @@ class BandGather:
         sb, se = self.pieces[k]
         if se <= sb:
             return
-        view = band[sb - self.begin: se - self.begin]
+        view = band[self.offsets[k]: self.offsets[k] + (se - sb)]
         if self.world == 1 or self.rank == self.dst:
             if full is not None:
                 full[sb:se].copy_(view, non_blocking=True)

@@ -892,6 +892,7 @@ def test_workspace_is_validated(rclib):
 
 
 @pytest.mark.parametrize("mode,extra,launcher", [("bands", ["--gather", "rgba8"], True), ("bands", [], False),
+                                                 ("bands", ["--band-layout", "interleaved"], False),
                                                  ("frames", ["--sequence"], True), ("frames", [], False)])
 def test_bench_two_ranks_share_one_gpu(mode, extra, launcher):
     """bench.py's N>1 launch contract with two ranks on this one GPU (gloo instead of RCCL, both ranks
@@ -917,7 +918,8 @@ def test_bench_two_ranks_share_one_gpu(mode, extra, launcher):
 
 
 @pytest.mark.parametrize("extra", [[], ["--gather", "rgba8", "--subbands", "3"], ["--gather-impl", "c"],
-                                   ["--gather-impl", "c", "--gather", "rgba8", "--subbands", "3"]])
+                                   ["--gather-impl", "c", "--gather", "rgba8", "--subbands", "3"],
+                                   ["--band-layout", "interleaved", "--gather", "rgba8"]])
 def test_bench_band_assembly_on_device_tensors_one_rank(extra):
     """--mode bands on ONE rank still renders the band piece by piece (y_offset / full_height) and
     assembles the pieces on device tensors under a one-rank RCCL process group: the assembled frame

@@ -44,7 +44,7 @@ def _worker(rank, world, port, w, h, n, out_path):
         dist.destroy_process_group()
 
 
-def _worker_overlap(rank, world, port, w, h, n, parts, out_path):
+def _worker_overlap(rank, world, port, w, h, n, parts, layout, out_path):
     os.environ["MASTER_ADDR"] = "127.0.0.1"
     os.environ["MASTER_PORT"] = str(port)
     dist.init_process_group("gloo", rank=rank, world_size=world)
@@ -52,14 +52,14 @@ def _worker_overlap(rank, world, port, w, h, n, parts, out_path):
         from oracle import binding as ob
         pos, rad, col = ob.generate_scene(n, 0)
         cam = ob.camera_data((0, 0, 20), (0.05, -0.1, 0), w, h)
-        g = sharding.BandGather(h, world, rank, parts=parts, dst=0)
+        g = sharding.BandGather(h, world, rank, parts=parts, dst=0, layout=layout)
         full = torch.zeros((h, w, 4), dtype=torch.float32) if rank == 0 else None
-        band = torch.zeros((g.end - g.begin, w, 4), dtype=torch.float32)
+        band = torch.zeros((g.rows, w, 4), dtype=torch.float32)
         g.post_receives(full)
         for k, (sb, se) in enumerate(g.pieces):
             if se > sb:
                 piece = ob.render(pos, rad, col, cam, w, se - sb, y_offset=sb, full_height=h, threads=2)
-                band[sb - g.begin: se - g.begin] = torch.from_numpy(piece)
+                band[g.offsets[k]: g.offsets[k] + (se - sb)] = torch.from_numpy(piece)
             g.piece_rendered(k, band, full)
         g.wait()
         dist.barrier()
@@ -69,11 +69,12 @@ def _worker_overlap(rank, world, port, w, h, n, parts, out_path):
         dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("world,h,parts", [(2, 96, 2), (3, 101, 3), (2, 5, 4)])
-def test_band_gather_with_overlap_pieces_gloo(oracle, tmp_path, world, h, parts):
+@pytest.mark.parametrize("world,h,parts,layout", [(2, 96, 2, "contiguous"), (3, 101, 3, "contiguous"), (2, 5, 4, "contiguous"),
+                                                  (2, 96, 2, "interleaved"), (3, 101, 2, "interleaved"), (2, 3, 2, "interleaved")])
+def test_band_gather_with_overlap_pieces_gloo(oracle, tmp_path, world, h, parts, layout):
     w, n = 96, 30
     out = str(tmp_path / "full.npy")
-    mp.spawn(_worker_overlap, args=(world, _free_port(), w, h, n, parts, out), nprocs=world, join=True)
+    mp.spawn(_worker_overlap, args=(world, _free_port(), w, h, n, parts, layout, out), nprocs=world, join=True)
     got = np.load(out)
     pos, rad, col = oracle.generate_scene(n, 0)
     cam = oracle.camera_data((0, 0, 20), (0.05, -0.1, 0), w, h)
@@ -99,6 +100,25 @@ def test_band_gather_gloo(oracle, tmp_path, world, h):
     cam = oracle.camera_data((0, 0, 20), (0.05, -0.1, 0), w, h)
     want = oracle.render(pos, rad, col, cam, w, h)
     assert np.array_equal(got.view(np.uint32), want.view(np.uint32))
+
+
+@pytest.mark.parametrize("layout", ["contiguous", "interleaved"])
+def test_rank_pieces_tile_the_frame(layout):
+    """Every row belongs to exactly one piece of one rank, whatever the height."""
+    for world in (1, 2, 3, 8):
+        for h in (0, 1, 5, 16, 101, 2160):
+            owner = np.zeros(h, dtype=np.int32)
+            for r in range(world):
+                g = sharding.BandGather(h, world, r, parts=3, layout=layout)
+                assert g.rows == sum(e - b for b, e in g.pieces)
+                for b, e in g.pieces:
+                    owner[b:e] += 1
+            assert (owner == 1).all()
+
+
+def test_interleaved_pieces_pair_outer_with_inner():
+    assert sharding.rank_pieces(160, 4, 0, layout="interleaved") == [(0, 20), (80, 100)]
+    assert sharding.rank_pieces(160, 4, 3, layout="interleaved") == [(60, 80), (140, 160)]
 
 
 def test_frames_round_robin():
