@@ -603,7 +603,7 @@ def main():
     # Floating-point work the kernel EXECUTES per test.  Tiled kernel, primary rays: the separable
     # filter T = fma(a_pixel, beta, r), r = fma(b_row, gamma, alpha) shared by the lane's P pixels,
     # then one input of the running maximum: (1 + 1/P) FMA (2 FLOP each) + 1.  Shadow rays (EXT,
-    # brute-force pass): h.e as mul + 2 FMA, then one max input: 6 FLOP, counted for hit pixels only
+    # brute-force pass): h.e as mul + 2 FMA (2 FMA in the dominant-axis form), then one max input: 6 (5) FLOP, counted for hit pixels only
     # (lanes of a wave with a hit that hold no hit pixel run the loop too and are not counted).
     # The exact re-tests of flagged pairs, ray set-up, shading and stores are not counted either.
     # Literal kernel: kernel.cu:53-58 as written, 21 FLOP to the discriminant.
@@ -611,12 +611,15 @@ def main():
     abi.check(lib.rc_device_info(local_rank, C.byref(cu_count), None, None))
     tiles = lambda p: -(-w // (16 * p)) * -(-rows // 16)       # noqa: E731  (the launcher's own rule)
     want = 5 * cu_count.value
-    ppl = 8 if (args.shading == "ref" and args.variant != "culled" and tiles(8) >= want) else (4 if tiles(4) >= want else 2)
+    want4 = 2 * want if (args.shading == "ext" and args.variant != "culled" and n < 2048) else want
+    ppl = 8 if (args.shading == "ref" and args.variant != "culled" and tiles(8) >= want) else (4 if tiles(4) >= want4 else 2)
     ppl = {"tiled2": 2, "tiled4": 4, "tiled8": 8 if args.shading == "ref" else 4}.get(args.variant, ppl)
     if args.variant == "literal":
         executed_flop, executed_shadow_flop = float(REF_FLOP_PER_TEST), float(REF_FLOP_PER_TEST)
     else:
-        executed_flop, executed_shadow_flop = 2.0 * (1.0 + 1.0 / ppl) + 1.0, 6.0
+        # shadow filter: the dominant-axis form (2 FMA + max input) from 1024 spheres or when forced, else mul + 2 FMA + max
+        axis = (args.tuning & abi.TUNE_SHADOW_AXIS_ON) or (n >= 1024 and not (args.tuning & abi.TUNE_SHADOW_AXIS_OFF))
+        executed_flop, executed_shadow_flop = 2.0 * (1.0 + 1.0 / ppl) + 1.0, (5.0 if axis else 6.0)
     secs = kernel_ms * 1e-3
     executed_tflops = (executed_flop * tests + executed_shadow_flop * shadow_tests) / secs / 1e12
     # counter-derived figures of this exact workload / shading / variant, if tools/profile.sh has been
