@@ -521,11 +521,16 @@ __device__ __forceinline__ RcLightRecord rc_prepass_light(const RcKernArgs &a, i
 // (1 + S)/g - (S - 2u).  Needed: S - 2u - 17.7 u |h| >= 0, which holds with a factor of 6 to spare.
 // Pixels without a shadow ray carry u = v = 0 and len = +inf (never flagged); forced lanes and
 // "always" spheres bypass the filter in both forms.
+//
+// A shadow ray asks for ANY occluder, so a pixel that is in shadow needs no further test: in the FAST form
+// its threshold becomes +inf (it stops flagging blocks), and once every shadow ray of the wave is in shadow
+// the wave leaves the loop (returns true; measured 3840x2160 x 1024: 0.720 vs 0.734 ms, 7680x4320 x 4096:
+// 10.4 vs 10.65 ms; the other form, used by small scenes, got 1 % slower with the check and goes without).  Both only ever skip tests whose outcome could not change a bit.
 template <int P, bool FAST>
-__device__ __forceinline__ void rc_shadow_blocks(const RcKernArgs &a, const float4 *s_rec, const unsigned *s_flag,
+__device__ __forceinline__ bool rc_shadow_blocks(const RcKernArgs &a, const float4 *s_rec, const unsigned *s_flag,
                                                  const float4 *s_exact, int base, int cn, int nblocks,
                                                  unsigned long long flag0_mask, unsigned long long forced_mask,
-                                                 const float (&fu)[P], const float (&fv)[P], const float (&flen)[P],
+                                                 const float (&fu)[P], const float (&fv)[P], float (&flen)[P],
                                                  const float (&ex)[P], const float (&ey)[P], const float (&ez)[P],
                                                  const float (&limit)[P], const int (&idx)[P], unsigned &shadowed)
 {
@@ -605,8 +610,18 @@ __device__ __forceinline__ void rc_shadow_blocks(const RcKernArgs &a, const floa
                     }
                 }
             }
+            if (FAST) {                            // large scenes only: at 64 spheres the check costs more than it saves
+                bool pending = false;              // a shadow ray of this lane still unoccluded (misses carry limit = -1)
+#pragma unroll
+                for (int p = 0; p < P; p++) pending = pending || (limit[p] >= 0.0f && !((shadowed >> p) & 1u));
+                if (__builtin_amdgcn_ballot_w64(pending) == 0ull) return true;
+#pragma unroll
+                for (int p = 0; p < P; p++)
+                    if ((shadowed >> p) & 1u) flen[p] = __builtin_inff();
+            }
         }
     }
+    return false;
 }
 
 // Hard-shadow pass of EXT mode: for every hit pixel, is any sphere other than the one hit
@@ -647,7 +662,7 @@ __device__ __forceinline__ void rc_shadow_pass(const RcKernArgs &a, char *lds,
     bool any_hit = false;
 #pragma unroll
     for (int p = 0; p < P; p++) any_hit = any_hit || (idx[p] != -1);
-    const bool wave_has_hits = __builtin_amdgcn_ballot_w64(any_hit) != 0ull;   // no hit pixel: no shadow rays
+    bool wave_has_hits = __builtin_amdgcn_ballot_w64(any_hit) != 0ull;   // no hit pixel: no shadow rays
 
     float cax = 0.0f, cay = 0.0f, caz = 0.0f, ccos = 1.0f, csin = 0.0f;
     bool cone_forced = (forced_mask != 0ull);
@@ -793,12 +808,14 @@ __device__ __forceinline__ void rc_shadow_pass(const RcKernArgs &a, char *lds,
         }
 
         if (!CULL && nblocks > 0) {
+            bool done;
             if (SHFAST && fast_axis >= 0)
-                rc_shadow_blocks<P, true>(a, s_rec, s_flag, s_exact, base, cn, nblocks, flag0_mask, forced_mask,
-                                          fu, fv, flen, ex, ey, ez, limit, idx, shadowed);
+                done = rc_shadow_blocks<P, true>(a, s_rec, s_flag, s_exact, base, cn, nblocks, flag0_mask, forced_mask,
+                                                 fu, fv, flen, ex, ey, ez, limit, idx, shadowed);
             else
-                rc_shadow_blocks<P, false>(a, s_rec, s_flag, s_exact, base, cn, nblocks, flag0_mask, forced_mask,
-                                           fu, fv, flen, ex, ey, ez, limit, idx, shadowed);
+                done = rc_shadow_blocks<P, false>(a, s_rec, s_flag, s_exact, base, cn, nblocks, flag0_mask, forced_mask,
+                                                  fu, fv, flen, ex, ey, ez, limit, idx, shadowed);
+            if (done) wave_has_hits = false;       // later chunks: this wave only keeps the barriers
         }
     }
 }
