@@ -614,6 +614,7 @@ def main():
     want4 = 2 * want if (args.shading == "ext" and args.variant != "culled" and n < 2048) else want
     ppl = 8 if (args.shading == "ref" and args.variant != "culled" and tiles(8) >= want) else (4 if tiles(4) >= want4 else 2)
     ppl = {"tiled2": 2, "tiled4": 4, "tiled8": 8 if args.shading == "ref" else 4}.get(args.variant, ppl)
+    axis = False
     if args.variant == "literal":
         executed_flop, executed_shadow_flop = float(REF_FLOP_PER_TEST), float(REF_FLOP_PER_TEST)
     else:
@@ -676,6 +677,9 @@ def main():
                 "kernel": ("rc_draw_tiled<%d,%s,false>" % (ppl, "true" if args.shading == "ext" else "false"))
                           if args.variant.startswith("tiled") else args.variant,
                 "kernel_ms": kernel_ms, "tests_per_launch": tests, "shadow_tests_per_launch": shadow_tests,
+                "shadow_tests_note": ("hit pixels x spheres (the algorithmic count); from 1024 spheres the shadow loop leaves "
+                                      "early for waves whose shadow rays are all occluded, so fewer are executed and frac is "
+                                      "an upper bound of the executed fraction in EXT mode") if (shadow_tests and axis) else None,
                 "tests_per_second": tests / secs,
                 # equivalent rates for comparisons, NOT roofline fractions: the same tests priced at the hoisted
                 # 7-FLOP form of kernel.cu:53-58 and at the 21 FLOP the reference (and the CPU baseline) execute
