@@ -25,6 +25,17 @@
 #define I_ADD3(i) "v_add3_u32 %" #i ", %" #i ", %8, %9\n"
 #define I_LSHLOR(i) "v_lshl_or_b32 %" #i ", %" #i ", %8, %9\n"
 #define I_CMP(i) "v_cmp_ge_f32 vcc, %" #i ", %8\n"
+#define I_PKFMAH(i) "v_pk_fma_f16 %" #i ", %" #i ", %8, %9\n"
+#define I_PKMAXH(i) "v_pk_max_f16 %" #i ", %" #i ", %8\n"
+#define I_PKMULH(i) "v_pk_mul_f16 %" #i ", %" #i ", %8\n"
+#define I_PKADDH(i) "v_pk_add_f16 %" #i ", %" #i ", %8\n"
+#define I_PKMAX3H(i) "v_pk_maximum3_f16 %" #i ", %" #i ", %8, %9\n"
+#define I_DOT2H(i) "v_dot2_f32_f16 %" #i ", %8, %9, %" #i "\n"
+#define I_DOT2CH(i) "v_dot2c_f32_f16 %" #i ", %8, %9\n"
+#define I_MAXIMUM3(i) "v_maximum3_f32 %" #i ", %" #i ", %8, %9\n"
+#define I_MAX3H(i) "v_max3_f16 %" #i ", %" #i ", %8, %9\n"
+#define I_FMAH(i) "v_fma_f16 %" #i ", %" #i ", %8, %9\n"
+#define I_PKMINI16(i) "v_pk_min_u16 %" #i ", %" #i ", %8\n"
 
 template <int KIND>
 __global__ __launch_bounds__(256) void k(float *out, int iters, float seed)
@@ -63,6 +74,8 @@ __global__ __launch_bounds__(256) void k(float *out, int iters, float seed)
         KIND8(10, I_OR3) KIND8(11, I_ANDOR) KIND8(12, I_MAX2) KIND8(13, I_MAX2ABS) KIND8(14, I_PKMAXI16)
         KIND8(15, I_MAX3I) KIND8(16, I_AND) KIND8(17, I_PERM) KIND8(18, I_FMAMIX) KIND8(19, I_MED3)
         KIND8(20, I_MIN3) KIND8(21, I_ADD3) KIND8(22, I_LSHLOR)
+        KIND8(30, I_PKFMAH) KIND8(31, I_PKMAXH) KIND8(32, I_PKMULH) KIND8(33, I_PKADDH) KIND8(34, I_PKMAX3H)
+        KIND8(35, I_DOT2H) KIND8(36, I_DOT2CH) KIND8(37, I_MAXIMUM3) KIND8(38, I_MAX3H) KIND8(39, I_FMAH) KIND8(40, I_PKMINI16)
         else if (KIND == 23) { REP16(asm volatile(I_CMP(0) I_CMP(1) I_CMP(2) I_CMP(3) I_CMP(4) I_CMP(5) I_CMP(6) I_CMP(7)
                          : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3), "+v"(a4), "+v"(a5), "+v"(a6), "+v"(a7) : "v"(b), "v"(c) : "vcc");) }
     }
@@ -126,5 +139,16 @@ int main()
     run<21>("v_add3_u32", 8, 8);
     run<22>("v_lshl_or_b32", 8, 8);
     run<23>("v_cmp_ge_f32 (vopc)", 8, 8);
+    run<30>("v_pk_fma_f16", 32, 8);
+    run<31>("v_pk_max_f16", 16, 8);
+    run<32>("v_pk_mul_f16", 16, 8);
+    run<33>("v_pk_add_f16", 16, 8);
+    run<34>("v_pk_maximum3_f16", 32, 8);
+    run<35>("v_dot2_f32_f16", 32, 8);
+    run<36>("v_dot2c_f32_f16", 32, 8);
+    run<37>("v_maximum3_f32", 16, 8);
+    run<38>("v_max3_f16", 16, 8);
+    run<39>("v_fma_f16", 16, 8);
+    run<40>("v_pk_min_u16", 16, 8);
     return 0;
 }
