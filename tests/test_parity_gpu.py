@@ -937,6 +937,25 @@ def test_bench_band_assembly_on_device_tensors_one_rank(extra):
     assert d["config"]["sharding"] == "bands"
 
 
+def test_bench_under_the_launcher_with_rccl_one_rank():
+    """The driver's multi-GPU launch line with one rank: torch.distributed.run, RCCL process group bound to
+    the device, barrier, MAX reduction and per-rank gather of the timed region, one JSON line."""
+    import json, socket, sys
+    s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
+    r = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "1",
+                        "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.join(ROOT, "bench.py"),
+                        "--gpus", "1", "--steps", "6", "--warmup", "2", "--no-cpu", "--no-extras", "--no-clock-ramp"],
+                       capture_output=True, text=True, timeout=400, env=env)
+    assert r.returncode == 0, r.stderr[-3000:]
+    lines = [l for l in r.stdout.splitlines() if l.strip()]
+    assert len(lines) == 1, r.stdout
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 1 and d["steps"] == 6 and d["scaling"] == "weak"
+    assert d["config"]["backend"] in ("nccl", None) and len(d["per_rank_step_ms"]) == 1
+    assert 0.0 < d["roofline"]["frac"] <= 1.0
+
+
 def test_c_gather_one_rank_assembles_pieces(oracle):
     """librc_gather.so with a one-rank communicator (ncclCommInitRank on this GPU): a band rendered in
     three pieces, each handed to rc_gather_piece, arrives in the full frame bit for bit."""
