@@ -52,6 +52,16 @@ __device__ __forceinline__ void rc_ray_dir(const RcKernArgs &a, float sx, float 
     dx = qx * inv; dy = qy * inv; dz = qz * inv;
 }
 
+// vec3::norm (vec3.h:168-176,89-92) of the un-normalised ray q of kernel.cu:49, in place: ONE reciprocal,
+// three multiplies.  Returns |q| as the reference rounds it.
+__device__ __forceinline__ float rc_normalise(float &x, float &y, float &z)
+{
+    const float len = sqrtf((x * x + y * y) + z * z);
+    const float inv = 1.0f / len;
+    x = x * inv; y = y * inv; z = z * inv;
+    return len;
+}
+
 // Per-sphere terms of kernel.cu:53-58 that do not depend on the ray (all primary rays
 // share the origin): v = o - pos, 2v (exact), 4c (exact scaling of c = v.v - r*r).
 struct RcExactSphere { float tvx, tvy, tvz, c4, near; };
@@ -354,10 +364,20 @@ struct RcRecord { float alpha, gamma, beta; bool always; };
 
 constexpr float kNever = -1.0e30f;   // record value that can never reach len
 
-__device__ __forceinline__ RcRecord rc_prepass_sphere(const RcKernArgs &a, int i, RcExactSphere *exact = nullptr)
+// centre and radius of one sphere as loaded from the scene arrays
+struct RcSphereIn { float px, py, pz, r; };
+
+__device__ __forceinline__ RcSphereIn rc_load_sphere(const RcKernArgs &a, int i)
 {
-    float px = a.position[3 * i + 0], py = a.position[3 * i + 1], pz = a.position[3 * i + 2];
-    float r = a.radius[i];
+    RcSphereIn s;
+    s.px = a.position[3 * i + 0]; s.py = a.position[3 * i + 1]; s.pz = a.position[3 * i + 2];
+    s.r = a.radius[i];
+    return s;
+}
+
+__device__ __forceinline__ RcRecord rc_prepass_values(const RcKernArgs &a, const RcSphereIn &in, RcExactSphere *exact = nullptr)
+{
+    const float px = in.px, py = in.py, pz = in.pz, r = in.r;
     float vx = a.ox - px, vy = a.oy - py, vz = a.oz - pz;
     float vv = (vx * vx + vy * vy) + vz * vz;
     float c = vv - r * r;                                   // the reference's c, as rounded
@@ -381,6 +401,11 @@ __device__ __forceinline__ RcRecord rc_prepass_sphere(const RcKernArgs &a, int i
                  !(fabsf(rec.gamma) < 0x1p40f);
     if (rec.always) { rec.alpha = kNever; rec.beta = 0.0f; rec.gamma = 0.0f; }
     return rec;
+}
+
+__device__ __forceinline__ RcRecord rc_prepass_sphere(const RcKernArgs &a, int i, RcExactSphere *exact = nullptr)
+{
+    return rc_prepass_values(a, rc_load_sphere(a, i), exact);
 }
 
 typedef float rc_f2 __attribute__((ext_vector_type(2)));
@@ -454,17 +479,37 @@ __device__ __forceinline__ void rc_visit_sphere(const RcKernArgs &a, const float
         if (pm[p] != 0ull) rc_exact_test(e, dx[p], dy[p], dz[p], sphere, minDist[p], idx[p]);
 }
 
+// Wave-wide minimum / maximum with every lane active, as DPP operands of the min / max instructions
+// themselves (two quad permutes, two row mirrors, two row broadcasts: six instructions and one
+// v_readlane instead of six LDS-crossbar shuffles with their address arithmetic).  After the mirrors
+// every lane holds its row's result; row_bcast15 / row_bcast31 carry lane 15 of rows 0 and 2 into rows 1
+// and 3 and lane 31 into rows 2 and 3, so lane 63 ends with the whole wave's.  Lanes a step does not
+// write keep `old` = their own value, the identity of min and max.  The result is wave-uniform (SGPR).
+template <int CTRL, int ROW_MASK>
+__device__ __forceinline__ float rc_dpp(float v)
+{
+    return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(__builtin_bit_cast(int, v), __builtin_bit_cast(int, v),
+                                                                 CTRL, ROW_MASK, 0xf, false));
+}
 __device__ __forceinline__ float rc_wave_min(float v)
 {
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) v = fminf(v, __shfl_xor(v, o, 64));
-    return v;
+    v = fminf(v, rc_dpp<0xB1, 0xf>(v));      // quad_perm:[1,0,3,2]
+    v = fminf(v, rc_dpp<0x4E, 0xf>(v));      // quad_perm:[2,3,0,1]
+    v = fminf(v, rc_dpp<0x141, 0xf>(v));     // row_half_mirror
+    v = fminf(v, rc_dpp<0x140, 0xf>(v));     // row_mirror
+    v = fminf(v, rc_dpp<0x142, 0xa>(v));     // row_bcast:15 into rows 1 and 3
+    v = fminf(v, rc_dpp<0x143, 0xc>(v));     // row_bcast:31 into rows 2 and 3
+    return __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), 63));
 }
 __device__ __forceinline__ float rc_wave_max(float v)
 {
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o, 64));
-    return v;
+    v = fmaxf(v, rc_dpp<0xB1, 0xf>(v));
+    v = fmaxf(v, rc_dpp<0x4E, 0xf>(v));
+    v = fmaxf(v, rc_dpp<0x141, 0xf>(v));
+    v = fmaxf(v, rc_dpp<0x140, 0xf>(v));
+    v = fmaxf(v, rc_dpp<0x142, 0xa>(v));
+    v = fmaxf(v, rc_dpp<0x143, 0xc>(v));
+    return __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), 63));
 }
 
 __device__ __forceinline__ float rc_wave_sum(float v)
@@ -733,11 +778,10 @@ __device__ __forceinline__ void rc_shadow_pass(const RcKernArgs &a, char *lds,
         const int cn = min(a.n - base, cap);
         const int cnb = (cn + kBlockSpheres - 1) & ~(kBlockSpheres - 1);
         __syncthreads();                           // primary records / previous chunk consumed
-        if (tid == 0) *s_has_always = 0;
-        __syncthreads();
         {
             float *rec = reinterpret_cast<float *>(s_rec);
             unsigned char *flagb = reinterpret_cast<unsigned char *>(s_flag);
+            bool any_always = false;
             for (int j = tid; j < cnb; j += kBlock) {
                 RcLightRecord r;
                 RcExactSphere ex = {0.0f, 0.0f, 0.0f, 0.0f, 0.0f};
@@ -752,12 +796,15 @@ __device__ __forceinline__ void rc_shadow_pass(const RcKernArgs &a, char *lds,
                 float *g = rec + (j >> 2) * 12 + (j & 3);
                 g[0] = r.hx; g[4] = r.hy; g[8] = r.hz;
                 flagb[j] = r.always ? 1 : 0;
-                if (r.always) atomicOr(s_has_always, 1);
+                any_always = any_always || r.always;
                 if (s_exact) s_exact[j] = make_float4(ex.tvx, ex.tvy, ex.tvz, ex.c4);
             }
+            const bool wave_always = __builtin_amdgcn_ballot_w64(any_always) != 0ull;
+            if ((tid & 63) == 0) s_has_always[tid >> 6] = wave_always ? 1 : 0;
         }
         __syncthreads();
-        const unsigned long long flag0_mask = (*s_has_always != 0) ? ~0ull : forced_mask;
+        const bool has_always = (s_has_always[0] | s_has_always[1] | s_has_always[2] | s_has_always[3]) != 0;
+        const unsigned long long flag0_mask = has_always ? ~0ull : forced_mask;
         const int nblocks = (wave_has_hits && !CULL) ? cnb / kBlockSpheres : 0;
 
         if (CULL && wave_has_hits) {
@@ -835,35 +882,56 @@ __device__ __forceinline__ void rc_tiled_body(const RcKernArgs &a, char *lds)
     const int wave = tid >> 6, lane = tid & 63;
     const int lx = lane & 7, ly = lane >> 3;
 
-    // One workgroup per (16P x 16)-pixel tile.  Many short workgroups beat fewer long ones
-    // here: hit-heavy tiles cost more than empty ones and the hardware dispatcher evens that
+    // One workgroup per (16P x 16)-pixel tile (grid = tiles_x x tiles_y).  Many short workgroups beat fewer
+    // long ones here: hit-heavy tiles cost more than empty ones and the hardware dispatcher evens that
     // out (2-8 tiles per workgroup measured 5-25 % slower at 3840x2160 x 1024 spheres even
     // though the sphere records would be built less often).
     {
-        const int tile = blockIdx.x;
-        const int tyi = tile / a.tiles_x, txi = tile - tyi * a.tiles_x;
+        // LAZY (brute-force REF kernels): the normalised direction d -- an IEEE square root, an IEEE
+        // division and three products per pixel -- and the wave tile's interval bounds are needed by the
+        // exact re-tests and the shading only, so they are evaluated when the wave first meets a flagged
+        // block; a wave over empty background never pays for them.  Until then (dx, dy, dz) hold the
+        // un-normalised q of kernel.cu:49.  EXT needs d for every pixel (plane test), the culled variant
+        // its bounds at once.
+        constexpr bool LAZY = !EXT && !CULL;
+        const int tyi = blockIdx.y, txi = blockIdx.x;
         const int x0 = txi * (2 * TW) + (wave & 1) * TW + lx;
         const int row = tyi * 16 + (wave >> 1) * 8 + ly;
         const int rowc = min(row, a.rows - 1);
 
+        // every global load of the prologue is issued here, ahead of the arithmetic that hides its latency:
+        // the sine-table entries and, in the brute-force variant, this thread's sphere of the first LDS chunk
+        const float sy = a.sin_y[rowc + a.y_offset];
+        float sxv[P];
+#pragma unroll
+        for (int p = 0; p < P; p++) sxv[p] = a.sin_x[min(x0 + 8 * p, a.width - 1)];
+        // (not in the 4-pixel EXT kernels: they sit at the 128-register limit and the four values would spill)
+        constexpr bool PREFETCH = !CULL && !(EXT && P >= 4);
+        RcSphereIn first_sphere = {0.0f, 0.0f, 0.0f, 0.0f};
+        if (PREFETCH && tid < a.n) first_sphere = rc_load_sphere(a, tid);
+
         float fa[P], len[P], dx[P], dy[P], dz[P], minDist[P];
         int idx[P];
         bool lane_forced = (a.cam_ok == 0);
-        const float sy = a.sin_y[rowc + a.y_offset];
         const float fb = sy;
 #pragma unroll
         for (int p = 0; p < P; p++) {
-            const int xc = min(x0 + 8 * p, a.width - 1);
-            const float sx = a.sin_x[xc];
-            // kernel.cu:49 + vec3::norm, exactly (same statements as rc_ray_dir, keeping |q|)
+            const float sx = sxv[p];
+            // kernel.cu:49, exactly (the statements of rc_ray_dir)
             float tx = a.rx * sx, ty = a.ry * sx, tz = a.rz * sx;
             tx = tx * a.aspect; ty = ty * a.aspect; tz = tz * a.aspect;
             float qx = a.fx + tx, qy = a.fy + ty, qz = a.fz + tz;
             const float wx = a.ux * sy, wy = a.uy * sy, wz = a.uz * sy;
             qx = qx + wx; qy = qy + wy; qz = qz + wz;
-            len[p] = sqrtf((qx * qx + qy * qy) + qz * qz);
-            const float inv = 1.0f / len[p];
-            dx[p] = qx * inv; dy[p] = qy * inv; dz[p] = qz * inv;
+            dx[p] = qx; dy[p] = qy; dz[p] = qz;
+            if (LAZY) {
+                // The filter's threshold: a LOWER bound of the reference's |q| (a lower threshold can only
+                // flag more).  The hardware square root is within one ulp, so times (1 - 2^-21) it is
+                // below sqrt(s)(1 - 2^-22) <= the correctly rounded value.
+                len[p] = __builtin_amdgcn_sqrtf((qx * qx + qy * qy) + qz * qz) * (1.0f - 0x1p-21f);
+            } else {
+                len[p] = rc_normalise(dx[p], dy[p], dz[p]);
+            }
             // filter inputs
             fa[p] = sx * a.aspect;
             const float Q = a.nF + fabsf(fa[p]) * a.nR + fabsf(fb) * a.nU;
@@ -879,9 +947,9 @@ __device__ __forceinline__ void rc_tiled_body(const RcKernArgs &a, char *lds)
         // and in b, so T <= alpha + max(tb_lo gamma, tb_hi gamma) + max(ta_lo beta, ta_hi beta) =
         // Tmax for every pixel of the tile.  A sphere whose Tmax, plus 16u of the summed magnitudes
         // for the roundings of T and Tmax, stays below tlen_min is flagged by no pixel of the tile.
-        float ta_lo, ta_hi, tb_lo, tb_hi, ta_abs, tb_abs, tlen_min;
+        float ta_lo = 0.0f, ta_hi = 0.0f, tb_lo = 0.0f, tb_hi = 0.0f, ta_abs = 0.0f, tb_abs = 0.0f, tlen_min = 0.0f;
         const bool tile_forced = (forced_mask != 0ull);
-        {
+        auto tile_bounds = [&]() {
             float lo = fa[0], hi = fa[0], lm = len[0];
 #pragma unroll
             for (int p = 1; p < P; p++) { lo = fminf(lo, fa[p]); hi = fmaxf(hi, fa[p]); lm = fminf(lm, len[p]); }
@@ -890,7 +958,9 @@ __device__ __forceinline__ void rc_tiled_body(const RcKernArgs &a, char *lds)
             tlen_min = rc_wave_min(lm);
             ta_abs = fmaxf(fabsf(ta_lo), fabsf(ta_hi));
             tb_abs = fmaxf(fabsf(tb_lo), fabsf(tb_hi));
-        }
+        };
+        bool have_d = !LAZY;                        // wave-uniform
+        if (!LAZY) tile_bounds();
 
         // Culled variant, level 1: bounds of the whole workgroup tile (the four wave tiles).
         float *s_wgb = reinterpret_cast<float *>(lds + rc_lds_bytes(cap));
@@ -902,8 +972,6 @@ __device__ __forceinline__ void rc_tiled_body(const RcKernArgs &a, char *lds)
         int total = a.n, bc0 = 0, bc1 = 0, bc2 = 0;
         const unsigned short *bsegs = nullptr;
         if (CULL && BINS) {
-            const int tile = blockIdx.x;
-            const int tyi = tile / a.tiles_x, txi = tile - tyi * a.tiles_x;
             const unsigned char *bin = a.bins + (size_t)((tyi >> 2) * a.bins_x + (txi >> 2)) * a.bin_stride;
             const int *bc = reinterpret_cast<const int *>(bin);
             bc0 = bc[0]; bc1 = bc[1]; bc2 = bc[2];
@@ -981,28 +1049,32 @@ __device__ __forceinline__ void rc_tiled_body(const RcKernArgs &a, char *lds)
                 if (lane == 0) s_cnt[wave] = count;
                 __syncthreads();
             } else {
-                __syncthreads();                       // previous chunk fully consumed
-                if (tid == 0) *s_has_always = 0;
-                __syncthreads();
+                if (base > 0) __syncthreads();         // previous chunk fully consumed
                 float *rec = reinterpret_cast<float *>(s_rec);
                 unsigned char *flagb = reinterpret_cast<unsigned char *>(s_flag);
+                bool any_always = false;
                 for (int j = tid; j < cnb; j += kBlock) {
                     RcRecord r;
                     RcExactSphere ex = {0.0f, 0.0f, 0.0f, 0.0f, 0.0f};
                     r.alpha = kNever; r.gamma = 0.0f; r.beta = 0.0f; r.always = false;
-                    if (j < cn) r = rc_prepass_sphere(a, base + j, &ex);
+                    // the first chunk's sphere of this thread was loaded at the top of the kernel
+                    if (j < cn) r = rc_prepass_values(a, (PREFETCH && base == 0 && j == tid) ? first_sphere : rc_load_sphere(a, base + j), &ex);
                     float *g = rec + (j >> 2) * 12 + (j & 3);
                     g[0] = r.alpha; g[4] = r.gamma; g[8] = r.beta;
                     flagb[j] = r.always ? 1 : 0;
-                    if (r.always) atomicOr(s_has_always, 1);
+                    any_always = any_always || r.always;
                     if (s_exact) {
                         s_exact[j] = make_float4(ex.tvx, ex.tvy, ex.tvz, ex.c4);
                         s_near[j] = (a.near_skip && !r.always && j < cn) ? ex.near : -__builtin_inff();
                     }
                 }
+                // one flag per wave ("this wave built an always-sphere"), read by everyone after the one barrier
+                const bool wave_always = __builtin_amdgcn_ballot_w64(any_always) != 0ull;
+                if (lane == 0) s_has_always[wave] = wave_always ? 1 : 0;
                 __syncthreads();
             }
-            const unsigned long long flag0_mask = CULL ? 0ull : ((*s_has_always != 0) ? ~0ull : forced_mask);
+            const bool has_always = !CULL && ((s_has_always[0] | s_has_always[1] | s_has_always[2] | s_has_always[3]) != 0);
+            const unsigned long long flag0_mask = CULL ? 0ull : (has_always ? ~0ull : forced_mask);
             const int nblocks = cnb / kBlockSpheres;
 
             if (CULL) {
@@ -1061,6 +1133,12 @@ __device__ __forceinline__ void rc_tiled_body(const RcKernArgs &a, char *lds)
 #pragma unroll
                 for (int p = 0; p < P; p++) flagged |= __builtin_amdgcn_ballot_w64(m[p] >= len[p]);
                 if (flagged != 0ull) {
+                    if (LAZY && !have_d) {             // first flagged block of this wave: see LAZY above
+#pragma unroll
+                        for (int p = 0; p < P; p++) rc_normalise(dx[p], dy[p], dz[p]);
+                        tile_bounds();
+                        have_d = true;
+                    }
                     // Rare path: some lane cannot rule out some sphere of this block.  Find which
                     // spheres: lane l tests sphere l of the block against the wave tile's interval
                     // bounds computed above (a superset of what any pixel flags), then each survivor
@@ -1108,9 +1186,13 @@ __device__ __forceinline__ void rc_tiled_body(const RcKernArgs &a, char *lds)
         }
 
         if (row < a.rows) {
+            // (EXT: the opaque copy makes the compiler form the column indices again from x0 here instead of
+            // carrying them, sign-extended, across the shadow pass in registers it does not have)
+            int xs = x0;
+            if (EXT) asm volatile("" : "+v"(xs));
 #pragma unroll
             for (int p = 0; p < P; p++) {
-                const int x = x0 + 8 * p;
+                const int x = xs + 8 * p;
                 if (x < a.width) {
                     float r = 0.0f, g = 0.0f, b = 0.0f;
                     if (EXT) {
@@ -1284,7 +1366,7 @@ static hipError_t rc_launch_tiled(RcKernArgs a, hipStream_t stream)
     a.lds_exact = (!a.cull && a.lds_cap <= RC_LDS_EXACT_MAX && !(a.tuning & RC_KTUNE_NO_LDS_EXACT)) ? 1 : 0;
     a.near_skip = (a.tuning & RC_KTUNE_NO_NEAR_SKIP) ? 0 : 1;
     const size_t lds_plain = a.lds_exact ? rc_lds_bytes_exact(a.lds_cap) : rc_lds_bytes(a.lds_cap);
-    const unsigned grid = (unsigned)rc_tile_count<P>(a);
+    const dim3 grid((unsigned)a.tiles_x, (unsigned)a.tiles_y);
     if (a.cull && a.bins) {
         // level 0: bins of 4 x 4 workgroup tiles; layout fixed here because it depends on P
         a.bins_x = (a.tiles_x + 3) / 4;
@@ -1302,17 +1384,17 @@ static hipError_t rc_launch_tiled(RcKernArgs a, hipStream_t stream)
     }
     if (a.ext_mode) {
         if constexpr (P <= 4) {
-            if (a.cull && a.bins) hipLaunchKernelGGL((rc_draw_tiled<P, true, true, true>), dim3(grid), dim3(256), rc_lds_bytes_cull(a.lds_cap, true), stream, a);
-            else if (a.cull) hipLaunchKernelGGL((rc_draw_tiled<P, true, true>), dim3(grid), dim3(256), rc_lds_bytes_cull(a.lds_cap, false), stream, a);
-            else if (a.shadow_fast) hipLaunchKernelGGL((rc_draw_tiled<P, true, false, false, true>), dim3(grid), dim3(256), lds_plain, stream, a);
-            else hipLaunchKernelGGL((rc_draw_tiled<P, true, false>), dim3(grid), dim3(256), lds_plain, stream, a);
+            if (a.cull && a.bins) hipLaunchKernelGGL((rc_draw_tiled<P, true, true, true>), grid, dim3(256), rc_lds_bytes_cull(a.lds_cap, true), stream, a);
+            else if (a.cull) hipLaunchKernelGGL((rc_draw_tiled<P, true, true>), grid, dim3(256), rc_lds_bytes_cull(a.lds_cap, false), stream, a);
+            else if (a.shadow_fast) hipLaunchKernelGGL((rc_draw_tiled<P, true, false, false, true>), grid, dim3(256), lds_plain, stream, a);
+            else hipLaunchKernelGGL((rc_draw_tiled<P, true, false>), grid, dim3(256), lds_plain, stream, a);
         } else {
             return hipErrorInvalidValue;           // EXT is built for <= 4 pixels per lane
         }
     } else {
-        if (a.cull && a.bins) hipLaunchKernelGGL((rc_draw_tiled<P, false, true, true>), dim3(grid), dim3(256), rc_lds_bytes_cull(a.lds_cap, true), stream, a);
-        else if (a.cull) hipLaunchKernelGGL((rc_draw_tiled<P, false, true>), dim3(grid), dim3(256), rc_lds_bytes_cull(a.lds_cap, false), stream, a);
-        else hipLaunchKernelGGL((rc_draw_tiled<P, false, false>), dim3(grid), dim3(256), lds_plain, stream, a);
+        if (a.cull && a.bins) hipLaunchKernelGGL((rc_draw_tiled<P, false, true, true>), grid, dim3(256), rc_lds_bytes_cull(a.lds_cap, true), stream, a);
+        else if (a.cull) hipLaunchKernelGGL((rc_draw_tiled<P, false, true>), grid, dim3(256), rc_lds_bytes_cull(a.lds_cap, false), stream, a);
+        else hipLaunchKernelGGL((rc_draw_tiled<P, false, false>), grid, dim3(256), lds_plain, stream, a);
     }
     return hipGetLastError();
 }
