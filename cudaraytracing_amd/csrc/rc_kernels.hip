@@ -257,6 +257,8 @@ __device__ __forceinline__ void rc_ext_shade(const RcKernArgs &a, int idx, float
     r = cr * c + spec; g = cg * c + spec; b = cb * c + spec;
 }
 
+typedef float rc_f4 __attribute__((ext_vector_type(4)));
+
 // D3D float -> UNORM8: NaN -> 0, clamp [0,1], *255, +0.5, truncate (DXManager.cpp:134,328).
 __device__ __forceinline__ unsigned rc_unorm8(float f)
 {
@@ -270,8 +272,12 @@ __device__ __forceinline__ void rc_store_pixel(const RcKernArgs &a, int x, int r
                                                float r, float g, float b)
 {
     // kernel.cu:78: (float*)((char*)surface + y*pitch) + 4*x ; alpha at :83
-    float4 *p = reinterpret_cast<float4 *>(reinterpret_cast<char *>(a.surface) + (size_t)row * a.pitch) + x;
-    *p = make_float4(r, g, b, 1.0f);
+    // Nontemporal: the surface is written once and not read back by this kernel, so the lines stream out of
+    // the L2 as they fill instead of waiting, dirty, for the write-back at the end of the kernel (measured on
+    // one box, same run: 1920x1080 x 64 15.5 -> 13.3 us, 1280x768 x 512 37.4 -> 36.0 us, 3840x2160 x 1024
+    // 345.5 -> 344.1 us; EXT 42.2 -> 40.5 us at 1920x1080 x 64).
+    rc_f4 *p = reinterpret_cast<rc_f4 *>(reinterpret_cast<char *>(a.surface) + (size_t)row * a.pitch) + x;
+    __builtin_nontemporal_store(rc_f4{r, g, b, 1.0f}, p);
     if (a.rgba8) {
         int orow = a.rgba8_flip ? (a.rows - 1 - row) : row;
         unsigned v = rc_unorm8(r) | (rc_unorm8(g) << 8) | (rc_unorm8(b) << 16) | (255u << 24);

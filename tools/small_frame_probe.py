@@ -1,7 +1,7 @@
 """Fixed cost of the small-frame configurations: frame time of 640x480 x 8 and 1920x1080 x 64 (REF and EXT) next to
 the same frames with NO spheres (ray set-up, record build of nothing, stores: everything but the test loop) and
 with the pixels-per-lane choice forced, all in one process so that the numbers share one clock state.
-    python tools/small_frame_probe.py [tuning_bits]"""
+    python tools/small_frame_probe.py [tuning_bits [config,config,... [ref,ext]]]"""
 import ctypes as C
 import os
 import sys
@@ -11,6 +11,8 @@ from cudaraytracing_amd import abi, configs  # noqa: E402
 from cudaraytracing_amd.host import Camera, DeviceBuffer, generate_scene  # noqa: E402
 
 tuning = int(sys.argv[1]) if len(sys.argv) > 1 else 0
+names = sys.argv[2].split(",") if len(sys.argv) > 2 else ["c1_640x480_n8", "c2_1920x1080_n64", "ref_1280x768_n512", "c3_3840x2160_n1024"]
+shadings = sys.argv[3].split(",") if len(sys.argv) > 3 else ["ref", "ext"]
 lib = abi.load()
 e0, e1 = C.c_void_p(), C.c_void_p()
 lib.rc_event_create(C.byref(e0)); lib.rc_event_create(C.byref(e1))
@@ -32,7 +34,7 @@ def timed(screen, scene, opts, warm, reps):
     return ms.value / reps * 1e3
 
 
-for name in ("c1_640x480_n8", "c2_1920x1080_n64", "ref_1280x768_n512", "c3_3840x2160_n1024"):
+for name in names:
     cfg = configs.CONFIGS[name]
     w, h = cfg["width"], cfg["height"]
     for n in (cfg["n"], 0):
@@ -45,7 +47,7 @@ for name in ("c1_640x480_n8", "c2_1920x1080_n64", "ref_1280x768_n512", "c3_3840x
         cam = Camera(w, h); cam.position, cam.rotation = cfg["position"], cfg["rotation"]
         scene.cam = cam.get_data()
         screen = abi.RcScreen(surf.ptr.value, w, h, w * 16)
-        for shading in ("ref", "ext"):
+        for shading in shadings:
             cells = []
             for vname, v in variants:
                 opts = abi.RcOpts(variant=v, tuning=tuning)
