@@ -7,6 +7,7 @@
 #include <hip/hip_runtime.h>
 
 #include <math.h>
+#include <cmath>
 #include <stdio.h>
 #include <string.h>
 
@@ -270,6 +271,13 @@ int rc_enqueue_frame(const rc_screen *screen, const rc_scene *scene, const rc_op
         a.pcx = x.plane_color.x; a.pcy = x.plane_color.y; a.pcz = x.plane_color.z;
         a.lgx = x.light_pos.x; a.lgy = x.light_pos.y; a.lgz = x.light_pos.z;
         a.specular = x.specular;
+        // per-frame constants, with the per-pixel code's own statements (this file is built without contraction;
+        // sqrtf and / are correctly rounded on the host as they are on the device)
+        const float inv = 1.0f / sqrtf((a.pnx * a.pnx + a.pny * a.pny) + a.pnz * a.pnz);
+        a.pux = a.pnx * inv; a.puy = a.pny * inv; a.puz = a.pnz * inv;
+        a.pu_il = 1.0f / sqrtf((a.pux * a.pux + a.puy * a.puy) + a.puz * a.puz);
+        a.plane_num = a.plane_h - ((a.pnx * a.ox + a.pny * a.oy) + a.pnz * a.oz);
+        a.plane_num_light = a.plane_h - ((a.pnx * a.lgx + a.pny * a.lgy) + a.pnz * a.lgz);
     }
 
     {
@@ -284,6 +292,25 @@ int rc_enqueue_frame(const rc_screen *screen, const rc_scene *scene, const rc_op
         auto in_range = [](float v) { return v > 0x1p-20f && v < 0x1p20f; };
         a.cam_ok = (in_range(a.nF) && in_range(a.nR) && in_range(a.nU) && fabsf(a.aspect) < 0x1p20f &&
                     fabsf(a.ox) < 0x1p60f && fabsf(a.oy) < 0x1p60f && fabsf(a.oz) < 0x1p60f) ? 1 : 0;
+        // Near-orthogonal basis (the reference's Camera always produces one): every lane's own check
+        //     Q = |F| + |a||R| + |b||U| <= 4 len,   2^-20 < len < 2^20,   len = |F + aR + bU| as rounded,
+        // holds for all a, b the tables can supply, so the kernels skip it.  With pairwise |cos| <= d = 2^-10:
+        //     len^2 >= (F^2 + a^2 R^2 + b^2 U^2) - d (2|a||F||R| + 2|b||F||U| + 2|a||b||R||U|) >= (1 - 2d)(F^2 + a^2 R^2 + b^2 U^2)
+        // (2xy <= x^2 + y^2 on each pair) and Q <= sqrt(3) sqrt(F^2 + a^2 R^2 + b^2 U^2), hence Q <= 1.74 len in real
+        // numbers; the float evaluations of Q (inputs rounded up by 1e-6) and of len (error <= 8 u Q) move that by
+        // parts in 10^6.  len >= 0.99 |F| and len <= Q <= |F| + |aspect||R| + |U| because |sin| <= 1 for a finite fov.
+        if (a.cam_ok) {
+            auto dotd = [](float x0, float y0, float z0, float x1, float y1, float z1) {
+                return fabs((double)x0 * x1 + (double)y0 * y1 + (double)z0 * z1);
+            };
+            const double d = 0x1p-10;
+            const double qmax = (double)a.nF + fabs((double)a.aspect) * a.nR + (double)a.nU;
+            if (std::isfinite(scene->cam.fov) && a.nF > 0x1p-18f && qmax < 0x1p18 &&
+                dotd(a.fx, a.fy, a.fz, a.rx, a.ry, a.rz) <= d * a.nF * a.nR &&
+                dotd(a.fx, a.fy, a.fz, a.ux, a.uy, a.uz) <= d * a.nF * a.nU &&
+                dotd(a.rx, a.ry, a.rz, a.ux, a.uy, a.uz) <= d * a.nR * a.nU)
+                a.cam_ok = 2;
+        }
     }
 
     int dev = 0, cus = 0;
@@ -790,6 +817,18 @@ extern "C" int rc_write_ppm(const char *path, const uint8_t *rgba8, size_t pitch
         snprintf(g_err, sizeof(g_err), "cannot finish writing %s", path);
         return RC_EINVAL;
     }
+    return RC_OK;
+}
+
+extern "C" int rc_selftest_math(int which, uint32_t first_bits, uint32_t count, unsigned long long *mismatches_dev,
+                                float *out_fast_dev, float *out_general_dev, void *stream)
+{
+    if (which != 0 && which != 1) return rc_fail_arg("rc_selftest_math: which must be 0 (sqrt) or 1 (reciprocal)");
+    if (!mismatches_dev) return rc_fail_arg("rc_selftest_math: null counter");
+    if ((uint64_t)first_bits + count > 0x100000000ull) return rc_fail_arg("rc_selftest_math: operand range wraps");
+    hipError_t e = rc_launch_selftest_math(which, first_bits, count, mismatches_dev, out_fast_dev, out_general_dev,
+                                           static_cast<hipStream_t>(stream));
+    if (e != hipSuccess) return rc_fail_hip(e, "self-test kernel launch");
     return RC_OK;
 }
 

@@ -37,7 +37,9 @@ struct RcKernArgs {
     float ux, uy, uz;        // cam.up
     float rx, ry, rz;        // cam.right
     float nF, nR, nU;        // upper bounds of |forward|, |right|, |up| (filter range check)
-    int cam_ok;              // 0: camera basis outside the range the filter is proven for
+    int cam_ok;              // 0: camera basis outside the range the filter is proven for (every lane takes the exact
+                             // path); 1: in range, each lane checks its own ray; 2: in range and so close to orthogonal
+                             // that no lane's ray can fail that check (see rc_enqueue_frame), which is then skipped
     // EXT mode (plane + point light + Phong + hard shadows; no counterpart in the reference)
     int tuning;              // RC_KTUNE_* bits
     int cull;                // 1: tile-culling variant of the tiled kernel
@@ -47,6 +49,12 @@ struct RcKernArgs {
     float pcx, pcy, pcz;
     float lgx, lgy, lgz;     // point light position
     float specular;
+    // per-frame constants of EXT mode, evaluated on the host with the statements the per-pixel code would use
+    // (IEEE binary32, one rounding per operation: the same bits as on the device)
+    float pux, puy, puz;     // plane normal normalised: pn * (1 / sqrt(pn.pn))
+    float pu_il;             // 1 / sqrt(pu.pu), the reciprocal length vec3::reflect divides by twice
+    float plane_num;         // plane_h - pn.o      numerator of the primary plane test
+    float plane_num_light;   // plane_h - pn.light  numerator of the plane's shadow test
     // culled variant: sphere records built once per frame by rc_launch_records (else NULL)
     const float4 *records;   // [n] {alpha, gamma, beta, always ? 1 : 0}
     const unsigned char *bins; // culled variant, level 0: per-bin sphere lists (else NULL); bins_bytes available
@@ -65,3 +73,6 @@ hipError_t rc_launch_draw(const RcKernArgs &a, int variant, int compute_units, h
 hipError_t rc_launch_records(const RcKernArgs &a, float4 *records, hipStream_t stream);
 hipError_t rc_launch_rgba8(const void *surface, size_t pitch, int width, int rows, void *out,
                            size_t out_pitch, int flip, hipStream_t stream);
+// Self-test of the short correctly-rounded sqrt (which = 0) / reciprocal (1) sequences against the general ones.
+hipError_t rc_launch_selftest_math(int which, uint32_t first_bits, uint32_t count, unsigned long long *mismatches,
+                                   float *out_fast, float *out_general, hipStream_t stream);

@@ -37,6 +37,63 @@ constexpr int kGroup = 4;              // spheres per filter group (48 bytes of 
 // Exact arithmetic (reference order of operations)
 // ---------------------------------------------------------------------------------------
 
+// Correctly rounded square root and reciprocal (what sqrtf(x) and 1.0f / x mean in IEEE binary32), shorter than
+// the compiler's general sequences because the operand is first checked to be a normal number well inside the
+// exponent range; anything else (zero, denormals, huge, tiny, infinities, NaN) takes the general sequence.
+//
+// rc_sqrt: the hardware's v_sqrt_f32 is within one ulp, so the correctly rounded root is s, its predecessor or
+// its successor; the exact residuals x - (s -+ 1ulp) s (one FMA each, no rounding in the product) decide which --
+// the core of the compiler's own expansion, minus its rescaling of small operands.
+// rc_rcp: one Newton step from v_rcp_f32 (within one ulp), r' = r + r (1 - x r) with the residual exact in an FMA,
+// then a second one: the first brings r within half an ulp plus 2^-46 relative, the second rounds correctly.
+// Both are compared against the general sequences for EVERY binary32 mantissa over the whole admitted exponent
+// range on the device itself (rc_selftest_math, tests/test_parity_gpu.py::test_fast_sqrt_rcp_exhaustive).
+__device__ __forceinline__ float rc_sqrt_core(float x)
+{
+    const float s = __builtin_amdgcn_sqrtf(x);
+    const float sd = __builtin_bit_cast(float, __builtin_bit_cast(int, s) - 1);
+    const float su = __builtin_bit_cast(float, __builtin_bit_cast(int, s) + 1);
+    const float rd = __builtin_fmaf(-sd, s, x);
+    const float ru = __builtin_fmaf(-su, s, x);
+    float r = (rd <= 0.0f) ? sd : s;
+    r = (ru > 0.0f) ? su : r;
+    return r;
+}
+
+__device__ __forceinline__ float rc_rcp_core(float x)
+{
+    float r = __builtin_amdgcn_rcpf(x);
+    r = __builtin_fmaf(__builtin_fmaf(-x, r, 1.0f), r, r);
+    r = __builtin_fmaf(__builtin_fmaf(-x, r, 1.0f), r, r);
+    return r;
+}
+
+__device__ __forceinline__ float rc_sqrt(float x)
+{
+    // wave-uniform choice: one scalar branch, no lane ever takes both paths
+    if (__builtin_amdgcn_ballot_w64(!(x >= 0x1p-96f && x < 0x1p96f)) == 0ull) return rc_sqrt_core(x);
+    asm volatile("" ::: "memory");                           // keeps the general sequence out of the fast path
+    return sqrtf(x);
+}
+
+__device__ __forceinline__ float rc_rcp(float x)
+{
+    const float ax = fabsf(x);
+    if (__builtin_amdgcn_ballot_w64(!(ax >= 0x1p-96f && ax < 0x1p96f)) == 0ull) return rc_rcp_core(x);
+    asm volatile("" ::: "memory");
+    return 1.0f / x;
+}
+
+// vec3::norm (vec3.h:168-176,89-92) of the un-normalised ray q of kernel.cu:49, in place: ONE reciprocal,
+// three multiplies.  Returns |q| as the reference rounds it.
+__device__ __forceinline__ float rc_normalise(float &x, float &y, float &z)
+{
+    const float len = rc_sqrt((x * x + y * y) + z * z);
+    const float inv = rc_rcp(len);
+    x = x * inv; y = y * inv; z = z * inv;
+    return len;
+}
+
 // kernel.cu:44-50 with sinf(xAngle), sinf(yAngle) supplied: forward + (right*sx)*aspect
 // + up*sy, then vec3::norm (vec3.h:168-176,89-92: ONE reciprocal, three multiplies).
 __device__ __forceinline__ void rc_ray_dir(const RcKernArgs &a, float sx, float sy,
@@ -47,19 +104,8 @@ __device__ __forceinline__ void rc_ray_dir(const RcKernArgs &a, float sx, float 
     float qx = a.fx + tx, qy = a.fy + ty, qz = a.fz + tz;
     float wx = a.ux * sy, wy = a.uy * sy, wz = a.uz * sy;
     qx = qx + wx; qy = qy + wy; qz = qz + wz;
-    float len = sqrtf((qx * qx + qy * qy) + qz * qz);
-    float inv = 1.0f / len;
-    dx = qx * inv; dy = qy * inv; dz = qz * inv;
-}
-
-// vec3::norm (vec3.h:168-176,89-92) of the un-normalised ray q of kernel.cu:49, in place: ONE reciprocal,
-// three multiplies.  Returns |q| as the reference rounds it.
-__device__ __forceinline__ float rc_normalise(float &x, float &y, float &z)
-{
-    const float len = sqrtf((x * x + y * y) + z * z);
-    const float inv = 1.0f / len;
-    x = x * inv; y = y * inv; z = z * inv;
-    return len;
+    rc_normalise(qx, qy, qz);
+    dx = qx; dy = qy; dz = qz;
 }
 
 // Per-sphere terms of kernel.cu:53-58 that do not depend on the ray (all primary rays
@@ -191,22 +237,26 @@ __device__ __forceinline__ void rc_plane_test(const RcKernArgs &a, float dx, flo
     if (!a.has_plane) return;
     float denom = rc_dot3(a.pnx, a.pny, a.pnz, dx, dy, dz);
     if (denom != 0.0f) {
-        float t = ((a.plane_h - rc_dot3(a.pnx, a.pny, a.pnz, a.ox, a.oy, a.oz)) / denom) - 0.000001f;
+        float t = (a.plane_num / denom) - 0.000001f;          // plane_num = plane_h - n.o (host, same statements)
         if (t > 0.0f && t < minDist) { minDist = t; idx = kPlaneIdx; }
     }
 }
 
-// Hit point, shadow-ray direction FROM the light, and the distance limit of the shadow test.
+// Hit point, shadow-ray direction FROM the light, and the distance |light - point|.  The shadow test's distance
+// limit is ldist - 0.001f (rc_shadow_limit); the shading divides by the same ldist again.
 __device__ __forceinline__ void rc_ext_ray(const RcKernArgs &a, float minDist, float dx, float dy, float dz,
-                                           float &ex, float &ey, float &ez, float &limit)
+                                           float &ex, float &ey, float &ez, float &ldist)
 {
     float px = a.ox + dx * minDist, py = a.oy + dy * minDist, pz = a.oz + dz * minDist;
     float lvx = a.lgx - px, lvy = a.lgy - py, lvz = a.lgz - pz;
-    float lightDist = sqrtf((lvx * lvx + lvy * lvy) + lvz * lvz);
-    float invL = 1.0f / lightDist;
+    float lightDist = rc_sqrt((lvx * lvx + lvy * lvy) + lvz * lvz);
+    float invL = rc_rcp(lightDist);
     ex = (px - a.lgx) * invL; ey = (py - a.lgy) * invL; ez = (pz - a.lgz) * invL;
-    limit = lightDist - 0.001f;
+    ldist = lightDist;
 }
+
+// Pixels that cast no shadow ray carry ldist = -1, hence a negative limit.
+__device__ __forceinline__ float rc_shadow_limit(float ldist) { return ldist - 0.001f; }
 
 // Plane as an occluder of the shadow ray (not when the plane itself was hit).
 __device__ __forceinline__ bool rc_plane_shadow(const RcKernArgs &a, int idx, float ex, float ey, float ez, float limit)
@@ -214,38 +264,43 @@ __device__ __forceinline__ bool rc_plane_shadow(const RcKernArgs &a, int idx, fl
     if (!a.has_plane || idx == kPlaneIdx) return false;
     float de = rc_dot3(a.pnx, a.pny, a.pnz, ex, ey, ez);
     if (de == 0.0f) return false;
-    float t = ((a.plane_h - rc_dot3(a.pnx, a.pny, a.pnz, a.lgx, a.lgy, a.lgz)) / de) - 0.000001f;
+    float t = (a.plane_num_light / de) - 0.000001f;           // plane_num_light = plane_h - n.light (host)
     return t > 0.0f && t < limit;
 }
 
+// ldist: |light - point| as rc_ext_ray returned it for this pixel, or a negative value when no shadow ray was
+// cast (shadows off): it is then evaluated here, by the same statements.
 __device__ __forceinline__ void rc_ext_shade(const RcKernArgs &a, int idx, float minDist,
-                                             float dx, float dy, float dz, bool shadowed,
+                                             float dx, float dy, float dz, bool shadowed, float ldist,
                                              float &r, float &g, float &b)
 {
     float px = a.ox + dx * minDist, py = a.oy + dy * minDist, pz = a.oz + dz * minDist;
-    float nx, ny, nz, cr, cg, cb;
+    float nx, ny, nz, cr, cg, cb, il;
     if (idx >= 0) {
         nx = px - a.position[3 * idx + 0]; ny = py - a.position[3 * idx + 1]; nz = pz - a.position[3 * idx + 2];
-        float inv = 1.0f / sqrtf((nx * nx + ny * ny) + nz * nz);
+        float inv = rc_rcp(rc_sqrt((nx * nx + ny * ny) + nz * nz));
         nx = nx * inv; ny = ny * inv; nz = nz * inv;
         cr = a.color[3 * idx + 0]; cg = a.color[3 * idx + 1]; cb = a.color[3 * idx + 2];
+        il = 0.0f;                                            // evaluated below, only if the pixel is lit
     } else {
-        float inv = 1.0f / sqrtf((a.pnx * a.pnx + a.pny * a.pny) + a.pnz * a.pnz);
-        nx = a.pnx * inv; ny = a.pny * inv; nz = a.pnz * inv;
+        // the plane's unit normal and the reciprocal of ITS length are per-frame constants (host, same statements)
+        nx = a.pux; ny = a.puy; nz = a.puz;
         if (rc_dot3(a.pnx, a.pny, a.pnz, dx, dy, dz) > 0.0f) { nx = nx * -1.0f; ny = ny * -1.0f; nz = nz * -1.0f; }
         cr = a.pcx; cg = a.pcy; cb = a.pcz;
+        il = a.pu_il;
     }
     float c = 0.2f, spec = 0.0f;
     if (!shadowed) {
         float lvx = a.lgx - px, lvy = a.lgy - py, lvz = a.lgz - pz;
-        float invL = 1.0f / sqrtf((lvx * lvx + lvy * lvy) + lvz * lvz);
+        if (!(ldist >= 0.0f)) ldist = rc_sqrt((lvx * lvx + lvy * lvy) + lvz * lvz);
+        float invL = rc_rcp(ldist);
         float ldx = lvx * invL, ldy = lvy * invL, ldz = lvz * invL;
         float diff = fmaxf(rc_dot3(nx, ny, nz, ldx, ldy, ldz), 0.0f);
         c = c + diff * 0.5f;
         // Ldir.reflect(N): N * Ldir.dot(N) / N.length() / N.length() * 2 - Ldir  (vec3.h:163-166)
         float dn = rc_dot3(ldx, ldy, ldz, nx, ny, nz);
         float tx = nx * dn, ty = ny * dn, tz = nz * dn;
-        float il = 1.0f / sqrtf((nx * nx + ny * ny) + nz * nz);
+        if (idx >= 0) il = rc_rcp(rc_sqrt((nx * nx + ny * ny) + nz * nz));
         tx = tx * il; ty = ty * il; tz = tz * il;
         tx = tx * il; ty = ty * il; tz = tz * il;
         tx = tx * 2.0f; ty = ty * 2.0f; tz = tz * 2.0f;
@@ -268,20 +323,33 @@ __device__ __forceinline__ unsigned rc_unorm8(float f)
     return (unsigned)(int)(f * 255.0f + 0.5f);
 }
 
-__device__ __forceinline__ void rc_store_pixel(const RcKernArgs &a, int x, int row,
-                                               float r, float g, float b)
+// Start of surface row `row` (kernel.cu:78: (char*)surface + y*pitch) and of the matching RGBA8 row (null
+// without a second surface): formed once per lane, every pixel of the lane lies in this row.
+struct RcRowPtr { char *f32; char *u8; };
+
+__device__ __forceinline__ RcRowPtr rc_row_ptr(const RcKernArgs &a, int row)
 {
-    // kernel.cu:78: (float*)((char*)surface + y*pitch) + 4*x ; alpha at :83
+    RcRowPtr rp;
+    rp.f32 = reinterpret_cast<char *>(a.surface) + (size_t)row * a.pitch;
+    rp.u8 = nullptr;
+    if (a.rgba8) {
+        const int orow = a.rgba8_flip ? (a.rows - 1 - row) : row;
+        rp.u8 = reinterpret_cast<char *>(a.rgba8) + (size_t)orow * a.rgba8_pitch;
+    }
+    return rp;
+}
+
+__device__ __forceinline__ void rc_store_pixel(const RcRowPtr &rp, int x, float r, float g, float b)
+{
+    // kernel.cu:78: (float*)(row start) + 4*x ; alpha at :83
     // Nontemporal: the surface is written once and not read back by this kernel, so the lines stream out of
     // the L2 as they fill instead of waiting, dirty, for the write-back at the end of the kernel (measured on
     // one box, same run: 1920x1080 x 64 15.5 -> 13.3 us, 1280x768 x 512 37.4 -> 36.0 us, 3840x2160 x 1024
     // 345.5 -> 344.1 us; EXT 42.2 -> 40.5 us at 1920x1080 x 64).
-    rc_f4 *p = reinterpret_cast<rc_f4 *>(reinterpret_cast<char *>(a.surface) + (size_t)row * a.pitch) + x;
-    __builtin_nontemporal_store(rc_f4{r, g, b, 1.0f}, p);
-    if (a.rgba8) {
-        int orow = a.rgba8_flip ? (a.rows - 1 - row) : row;
-        unsigned v = rc_unorm8(r) | (rc_unorm8(g) << 8) | (rc_unorm8(b) << 16) | (255u << 24);
-        *reinterpret_cast<unsigned *>(reinterpret_cast<char *>(a.rgba8) + (size_t)orow * a.rgba8_pitch + 4 * (size_t)x) = v;
+    __builtin_nontemporal_store(rc_f4{r, g, b, 1.0f}, reinterpret_cast<rc_f4 *>(rp.f32) + x);
+    if (rp.u8) {
+        const unsigned v = rc_unorm8(r) | (rc_unorm8(g) << 8) | (rc_unorm8(b) << 16) | (255u << 24);
+        *(reinterpret_cast<unsigned *>(rp.u8) + x) = v;
     }
 }
 
@@ -311,9 +379,11 @@ __global__ __launch_bounds__(256) void rc_draw_literal(RcKernArgs a)
         rc_plane_test(a, dx, dy, dz, minDist, idx);
         if (idx != -1) {
             bool shadowed = false;
+            float ldist = -1.0f;
             if (a.shadows) {
-                float ex, ey, ez, limit;
-                rc_ext_ray(a, minDist, dx, dy, dz, ex, ey, ez, limit);
+                float ex, ey, ez;
+                rc_ext_ray(a, minDist, dx, dy, dz, ex, ey, ez, ldist);
+                const float limit = rc_shadow_limit(ldist);
                 for (int i = 0; i < a.n; i++) {
                     if (i == idx) continue;
                     RcExactSphere e = rc_exact_sphere_from(a, i, a.lgx, a.lgy, a.lgz);
@@ -322,12 +392,12 @@ __global__ __launch_bounds__(256) void rc_draw_literal(RcKernArgs a)
                 }
                 if (rc_plane_shadow(a, idx, ex, ey, ez, limit)) shadowed = true;
             }
-            rc_ext_shade(a, idx, minDist, dx, dy, dz, shadowed, r, g, b);
+            rc_ext_shade(a, idx, minDist, dx, dy, dz, shadowed, ldist, r, g, b);
         }
     } else if (idx >= 0) {
         rc_shade(a, idx, minDist, dx, dy, dz, r, g, b);
     }
-    rc_store_pixel(a, x, row, r, g, b);
+    rc_store_pixel(rc_row_ptr(a, row), x, r, g, b);
 }
 
 namespace {
@@ -583,7 +653,7 @@ __device__ __forceinline__ bool rc_shadow_blocks(const RcKernArgs &a, const floa
                                                  unsigned long long flag0_mask, unsigned long long forced_mask,
                                                  const float (&fu)[P], const float (&fv)[P], float (&flen)[P],
                                                  const float (&ex)[P], const float (&ey)[P], const float (&ez)[P],
-                                                 const float (&limit)[P], const int (&idx)[P], unsigned &shadowed)
+                                                 const float (&ldist)[P], const int (&idx)[P], unsigned &shadowed)
 {
     for (int blk = 0; blk < nblocks; blk++) {
         float m[P];
@@ -657,14 +727,14 @@ __device__ __forceinline__ bool rc_shadow_blocks(const RcKernArgs &a, const floa
 #pragma unroll
                     for (int p = 0; p < P; p++) {
                         const float dist = rc_exact_dist(e, ex[p], ey[p], ez[p]);
-                        if (base + j != idx[p] && dist > 0.0f && dist < limit[p]) shadowed |= 1u << p;
+                        if (base + j != idx[p] && dist > 0.0f && dist < rc_shadow_limit(ldist[p])) shadowed |= 1u << p;
                     }
                 }
             }
             if (FAST) {                            // large scenes only: at 64 spheres the check costs more than it saves
-                bool pending = false;              // a shadow ray of this lane still unoccluded (misses carry limit = -1)
+                bool pending = false;              // a shadow ray of this lane still unoccluded (misses carry ldist = -1)
 #pragma unroll
-                for (int p = 0; p < P; p++) pending = pending || (limit[p] >= 0.0f && !((shadowed >> p) & 1u));
+                for (int p = 0; p < P; p++) pending = pending || (ldist[p] >= 0.0f && !((shadowed >> p) & 1u));
                 if (__builtin_amdgcn_ballot_w64(pending) == 0ull) return true;
 #pragma unroll
                 for (int p = 0; p < P; p++)
@@ -693,7 +763,7 @@ __device__ __forceinline__ bool rc_shadow_blocks(const RcKernArgs &a, const floa
 template <int P, bool CULL, bool SHFAST>
 __device__ __forceinline__ void rc_shadow_pass(const RcKernArgs &a, char *lds,
                                                const float (&ex)[P], const float (&ey)[P], const float (&ez)[P],
-                                               const float (&limit)[P], const int (&idx)[P], unsigned &shadowed)
+                                               const float (&ldist)[P], const int (&idx)[P], unsigned &shadowed)
 {
     const int cap = a.lds_cap;
     float4 *s_rec = reinterpret_cast<float4 *>(lds);
@@ -854,7 +924,7 @@ __device__ __forceinline__ void rc_shadow_pass(const RcKernArgs &a, char *lds,
                     for (int p = 0; p < P; p++) {
                         if (pm[p] == 0ull) continue;
                         const float dist = rc_exact_dist(e, ex[p], ey[p], ez[p]);
-                        if (base + j != idx[p] && dist > 0.0f && dist < limit[p]) shadowed |= 1u << p;
+                        if (base + j != idx[p] && dist > 0.0f && dist < rc_shadow_limit(ldist[p])) shadowed |= 1u << p;
                     }
                 }
             }
@@ -864,10 +934,10 @@ __device__ __forceinline__ void rc_shadow_pass(const RcKernArgs &a, char *lds,
             bool done;
             if (SHFAST && fast_axis >= 0)
                 done = rc_shadow_blocks<P, true>(a, s_rec, s_flag, s_exact, base, cn, nblocks, flag0_mask, forced_mask,
-                                                 fu, fv, flen, ex, ey, ez, limit, idx, shadowed);
+                                                 fu, fv, flen, ex, ey, ez, ldist, idx, shadowed);
             else
                 done = rc_shadow_blocks<P, false>(a, s_rec, s_flag, s_exact, base, cn, nblocks, flag0_mask, forced_mask,
-                                                  fu, fv, flen, ex, ey, ez, limit, idx, shadowed);
+                                                  fu, fv, flen, ex, ey, ez, ldist, idx, shadowed);
             if (done) wave_has_hits = false;       // later chunks: this wave only keeps the barriers
         }
     }
@@ -940,8 +1010,10 @@ __device__ __forceinline__ void rc_tiled_body(const RcKernArgs &a, char *lds)
             }
             // filter inputs
             fa[p] = sx * a.aspect;
-            const float Q = a.nF + fabsf(fa[p]) * a.nR + fabsf(fb) * a.nU;
-            if (!(Q <= 4.0f * len[p]) || !(len[p] > 0x1p-20f) || !(len[p] < 0x1p20f)) lane_forced = true;
+            if (a.cam_ok != 2) {                    // 2: the host has shown that no ray of this frame can fail the check
+                const float Q = a.nF + fabsf(fa[p]) * a.nR + fabsf(fb) * a.nU;
+                if (!(Q <= 4.0f * len[p]) || !(len[p] > 0x1p-20f) || !(len[p] < 0x1p20f)) lane_forced = true;
+            }
             minDist[p] = 10000.0f;
             idx[p] = -1;
         }
@@ -1174,24 +1246,28 @@ __device__ __forceinline__ void rc_tiled_body(const RcKernArgs &a, char *lds)
         }
 
         unsigned shadowed = 0u;                     // bit p: pixel p of this lane is in shadow
+        float ldist[P];                             // EXT: |light - point| of the pixel's shadow ray, -1 without one
+#pragma unroll
+        for (int p = 0; p < P; p++) ldist[p] = -1.0f;
         if (EXT) {
 #pragma unroll
             for (int p = 0; p < P; p++) rc_plane_test(a, dx[p], dy[p], dz[p], minDist[p], idx[p]);
             if (a.shadows) {
-                float ex[P], ey[P], ez[P], limit[P];
+                float ex[P], ey[P], ez[P];
 #pragma unroll
                 for (int p = 0; p < P; p++) {
-                    ex[p] = 0.0f; ey[p] = 0.0f; ez[p] = 0.0f; limit[p] = -1.0f;   // misses cast no shadow ray
-                    if (idx[p] != -1) rc_ext_ray(a, minDist[p], dx[p], dy[p], dz[p], ex[p], ey[p], ez[p], limit[p]);
+                    ex[p] = 0.0f; ey[p] = 0.0f; ez[p] = 0.0f;                      // misses cast no shadow ray
+                    if (idx[p] != -1) rc_ext_ray(a, minDist[p], dx[p], dy[p], dz[p], ex[p], ey[p], ez[p], ldist[p]);
                 }
-                rc_shadow_pass<P, CULL, SHFAST>(a, lds, ex, ey, ez, limit, idx, shadowed);
 #pragma unroll
                 for (int p = 0; p < P; p++)
-                    if (idx[p] != -1 && rc_plane_shadow(a, idx[p], ex[p], ey[p], ez[p], limit[p])) shadowed |= 1u << p;
+                    if (idx[p] != -1 && rc_plane_shadow(a, idx[p], ex[p], ey[p], ez[p], rc_shadow_limit(ldist[p]))) shadowed |= 1u << p;
+                rc_shadow_pass<P, CULL, SHFAST>(a, lds, ex, ey, ez, ldist, idx, shadowed);
             }
         }
 
         if (row < a.rows) {
+            const RcRowPtr rowp = rc_row_ptr(a, row);
             // (EXT: the opaque copy makes the compiler form the column indices again from x0 here instead of
             // carrying them, sign-extended, across the shadow pass in registers it does not have)
             int xs = x0;
@@ -1211,12 +1287,12 @@ __device__ __forceinline__ void rc_tiled_body(const RcKernArgs &a, char *lds)
                             if (SHFAST)
                                 rc_ray_dir(a, *(volatile const float *)(a.sin_x + x), *(volatile const float *)(a.sin_y + row + a.y_offset),
                                            rdx, rdy, rdz);
-                            rc_ext_shade(a, idx[p], minDist[p], rdx, rdy, rdz, (shadowed >> p) & 1u, r, g, b);
+                            rc_ext_shade(a, idx[p], minDist[p], rdx, rdy, rdz, (shadowed >> p) & 1u, ldist[p], r, g, b);
                         }
                     } else if (idx[p] >= 0) {
                         rc_shade(a, idx[p], minDist[p], dx[p], dy[p], dz[p], r, g, b);
                     }
-                    rc_store_pixel(a, x, row, r, g, b);
+                    rc_store_pixel(rowp, x, r, g, b);
                 }
             }
         }
@@ -1335,6 +1411,21 @@ __global__ __launch_bounds__(256) void rc_rgba8_kernel(const char *surface, size
     *reinterpret_cast<unsigned *>(out + (size_t)orow * out_pitch + 4 * (size_t)x) = o;
 }
 
+// Device self-test of rc_sqrt_core / rc_rcp_core: operand i has the bit pattern first_bits + i; counts the operands
+// on which the short sequence and the compiler's general one (sqrtf, 1.0f / x) differ in any bit.
+__global__ __launch_bounds__(256) void rc_selftest_math_kernel(int which, uint32_t first_bits, uint32_t count,
+                                                               unsigned long long *mismatches, float *out_fast, float *out_general)
+{
+    const uint32_t i = blockIdx.x * 256u + threadIdx.x;
+    if (i >= count) return;
+    const float x = __builtin_bit_cast(float, first_bits + i);
+    const float fast = which ? rc_rcp_core(x) : rc_sqrt_core(x);
+    const float general = which ? 1.0f / x : sqrtf(x);
+    if (__builtin_bit_cast(uint32_t, fast) != __builtin_bit_cast(uint32_t, general)) atomicAdd(mismatches, 1ull);
+    if (out_fast) out_fast[i] = fast;
+    if (out_general) out_general[i] = general;
+}
+
 // ---------------------------------------------------------------------------------------
 // Launchers (host)
 // ---------------------------------------------------------------------------------------
@@ -1446,5 +1537,14 @@ hipError_t rc_launch_rgba8(const void *surface, size_t pitch, int width, int row
     hipLaunchKernelGGL(rc_rgba8_kernel, grid, dim3(256), 0, stream,
                        reinterpret_cast<const char *>(surface), pitch, width, rows,
                        reinterpret_cast<char *>(out), out_pitch, flip);
+    return hipGetLastError();
+}
+
+hipError_t rc_launch_selftest_math(int which, uint32_t first_bits, uint32_t count, unsigned long long *mismatches,
+                                   float *out_fast, float *out_general, hipStream_t stream)
+{
+    if (count == 0) return hipSuccess;
+    hipLaunchKernelGGL(rc_selftest_math_kernel, dim3((count + 255u) / 256u), dim3(256), 0, stream, which, first_bits, count,
+                       mismatches, out_fast, out_general);
     return hipGetLastError();
 }

@@ -311,6 +311,15 @@ int rc_ctx_write_ppm(rc_ctx *ctx, const char *path);
 const rc_screen *rc_ctx_screen(const rc_ctx *ctx);
 const rc_scene *rc_ctx_scene(const rc_ctx *ctx);
 
+/* Diagnostic, no counterpart in the reference.  The kernels evaluate some correctly rounded square roots and
+ * reciprocals (vec3::norm, vec3.h:168-176,89-92) with sequences shorter than the compiler's general ones, valid for
+ * normal operands with 2^-96 <= |x| < 2^96 (others take the general sequence).  This runs both on the `count`
+ * operands whose bit patterns are first_bits, first_bits + 1, ... and ADDS the number of operands on which they
+ * differ to *mismatches_dev (device memory, 8 bytes, zeroed by the caller); the two result arrays (device, `count`
+ * floats each) are optional.  which: 0 = square root, 1 = reciprocal.  Enqueue only. */
+int rc_selftest_math(int which, uint32_t first_bits, uint32_t count, unsigned long long *mismatches_dev,
+                     float *out_fast_dev, float *out_general_dev, void *stream);
+
 const char *rc_last_error_string(void);
 /* RC_ABI_VERSION the library was built with */
 int rc_abi_version(void);
