@@ -28,6 +28,28 @@
 
 #pragma clang fp contract(off)
 
+// Work counters of an instrumented build (hipcc -DRC_COUNT_TESTS, tools/count_tests.py; never in the shipped
+// library): lane 0 of a wave adds to a device-global tally at the wave-uniform points marked RC_COUNT below.
+// Slots: 0 primary blocks of 32 spheres run (x 64 lanes x P pixels x 32 = tests), 1 primary blocks flagged,
+// 2 spheres visited (per-pixel filter repeated), 3 pixel columns x spheres given the exact test (x 64 lanes),
+// 4 shadow blocks run, 5 shadow blocks flagged, 6 shadow spheres visited, 7 shadow spheres given the exact test
+// (x P columns x 64 lanes), 8 waves, 9 waves with a shadow ray, 10 waves that left the shadow loop early.
+#ifdef RC_COUNT_TESTS
+__device__ unsigned long long rc_counters[16];
+#define RC_COUNT(slot, n) do { if ((threadIdx.x & 63) == 0) atomicAdd(&rc_counters[slot], (unsigned long long)(n)); } while (0)
+extern "C" int rc_counters_fetch(unsigned long long *host16, int reset)
+{
+    if (hipMemcpyFromSymbol(host16, HIP_SYMBOL(rc_counters), sizeof(rc_counters)) != hipSuccess) return -1;
+    if (reset) {
+        const unsigned long long zero[16] = {0};
+        if (hipMemcpyToSymbol(HIP_SYMBOL(rc_counters), zero, sizeof(zero)) != hipSuccess) return -1;
+    }
+    return 0;
+}
+#else
+#define RC_COUNT(slot, n) do { } while (0)
+#endif
+
 namespace {
 
 constexpr int kBlock = 256;            // 4 waves, one per SIMD; >= 2 workgroups per CU
@@ -536,6 +558,7 @@ __device__ __forceinline__ void rc_visit_sphere(const RcKernArgs &a, const float
         pm[p] = (flag | all_mask) & (~far | forced_lanes);
         any |= pm[p];
     }
+    RC_COUNT(2, 1);
     if (any == 0ull) return;
     RcExactSphere e;
     if (s_exact) {
@@ -552,7 +575,7 @@ __device__ __forceinline__ void rc_visit_sphere(const RcKernArgs &a, const float
     // the exact test only for pixel columns in which some lane still flags the sphere
 #pragma unroll
     for (int p = 0; p < P; p++)
-        if (pm[p] != 0ull) rc_exact_test(e, dx[p], dy[p], dz[p], sphere, minDist[p], idx[p]);
+        if (pm[p] != 0ull) { RC_COUNT(3, 1); rc_exact_test(e, dx[p], dy[p], dz[p], sphere, minDist[p], idx[p]); }
 }
 
 // Wave-wide minimum / maximum with every lane active, as DPP operands of the min / max instructions
@@ -647,15 +670,28 @@ __device__ __forceinline__ RcLightRecord rc_prepass_light(const RcKernArgs &a, i
 // its threshold becomes +inf (it stops flagging blocks), and once every shadow ray of the wave is in shadow
 // the wave leaves the loop (returns true; measured 3840x2160 x 1024: 0.720 vs 0.734 ms, 7680x4320 x 4096:
 // 10.4 vs 10.65 ms; the other form, used by small scenes, got 1 % slower with the check and goes without).  Both only ever skip tests whose outcome could not change a bit.
+//
+// Which spheres of a flagged block?  In the FAST form, as in the primary search, lane l tests sphere l of the
+// block against interval bounds of the wave's filter inputs: T is linear in u and in v, so with the inputs of
+// every shadow ray of the wave inside [lo, hi] per component,
+//      T <= R0 + max(u_lo R1, u_hi R1) + max(v_lo R2, v_hi R2)
+// for every pixel; a sphere whose bound, plus 16u of the summed magnitudes for the roundings of T (three) and of
+// the bound (five), stays below the wave's smallest threshold is flagged by no pixel.  Survivors get the
+// per-pixel filter and, if a lane still flags them, the exact test (measured: finding the spheres by
+// re-evaluating the whole block per pixel was 7 of 38 us at 1920x1080 x 64 and 8 % of 3840x2160 x 1024).
+struct RcShadowBounds { float lo1, hi1, lo2, hi2, abs1, abs2, thr_min; };
+
 template <int P, bool FAST>
 __device__ __forceinline__ bool rc_shadow_blocks(const RcKernArgs &a, const float4 *s_rec, const unsigned *s_flag,
                                                  const float4 *s_exact, int base, int cn, int nblocks,
                                                  unsigned long long flag0_mask, unsigned long long forced_mask,
+                                                 const RcShadowBounds &wb,
                                                  const float (&fu)[P], const float (&fv)[P], float (&flen)[P],
                                                  const float (&ex)[P], const float (&ey)[P], const float (&ez)[P],
                                                  const float (&ldist)[P], const int (&idx)[P], unsigned &shadowed)
 {
     for (int blk = 0; blk < nblocks; blk++) {
+        RC_COUNT(4, 1);
         float m[P];
 #pragma unroll
         for (int p = 0; p < P; p++) m[p] = FAST ? -__builtin_inff() : 0.0f;
@@ -684,6 +720,58 @@ __device__ __forceinline__ bool rc_shadow_blocks(const RcKernArgs &a, const floa
 #pragma unroll
         for (int p = 0; p < P; p++) flagged |= __builtin_amdgcn_ballot_w64(m[p] >= (FAST ? flen[p] : 1.0f));
         if (flagged != 0ull) {
+            RC_COUNT(5, 1);
+            if constexpr (FAST) {
+            const float *rec = reinterpret_cast<const float *>(s_rec);
+            const unsigned char *flagb = reinterpret_cast<const unsigned char *>(s_flag);
+            const int lane = threadIdx.x & 63;
+            const int jl = blk * kBlockSpheres + (lane & (kBlockSpheres - 1));
+            unsigned long long cand_mask;
+            {
+                const float *g = rec + (jl >> 2) * 12 + (jl & 3);
+                const float r0 = g[0], r1 = g[4], r2 = g[8];
+                const float tmax = (r0 + fmaxf(wb.lo1 * r1, wb.hi1 * r1)) + fmaxf(wb.lo2 * r2, wb.hi2 * r2);
+                const float mag = (fabsf(r0) + wb.abs1 * fabsf(r1)) + wb.abs2 * fabsf(r2);
+                const bool c = (lane < kBlockSpheres) && (jl < cn) &&
+                               (forced_mask != 0ull || flagb[jl] != 0 || !(tmax + 0x1p-20f * mag < wb.thr_min));
+                cand_mask = __builtin_amdgcn_ballot_w64(c);
+            }
+            while (cand_mask != 0ull) {
+                const int bit = __builtin_ctzll(cand_mask);
+                cand_mask &= cand_mask - 1ull;
+                const int j = blk * kBlockSpheres + bit;
+                const float *g = rec + (j >> 2) * 12 + (j & 3);
+                const float h0 = g[0], h1 = g[4], h2 = g[8];
+                const unsigned long long all_mask = (flagb[j] != 0) ? ~0ull : forced_mask;
+                unsigned long long any = all_mask;
+#pragma unroll
+                for (int p = 0; p < P; p++) {
+                    const float t = FAST ? __builtin_fmaf(fu[p], h1, __builtin_fmaf(fv[p], h2, h0))
+                                         : __builtin_fmaf(ez[p], h2, __builtin_fmaf(ey[p], h1, ex[p] * h0));
+                    // (masking out the pixels that lie on sphere j itself -- they always pass their own sphere's filter and
+                    // are excluded from its shadow test -- saves exact tests but measured slower: 680 vs 673.5 us)
+                    any |= __builtin_amdgcn_ballot_w64(t >= (FAST ? flen[p] : 1.0f));
+                }
+                RC_COUNT(6, 1);
+                if (any == 0ull) continue;
+                RC_COUNT(7, 1);
+                RcExactSphere e;
+                if (s_exact) {
+                    const float4 v = s_exact[j];
+                    e.tvx = v.x; e.tvy = v.y; e.tvz = v.z; e.c4 = v.w;
+                } else {
+                    e = rc_exact_sphere_from(a, base + j, a.lgx, a.lgy, a.lgz);
+                }
+#pragma unroll
+                for (int p = 0; p < P; p++) {
+                    const float dist = rc_exact_dist(e, ex[p], ey[p], ez[p]);
+                    if (base + j != idx[p] && dist > 0.0f && dist < rc_shadow_limit(ldist[p])) shadowed |= 1u << p;
+                }
+            }
+            } else {
+                // three-product form (small scenes): the interval bound over (ex, ey, ez) is too loose to pay (measured:
+                // 1920x1080 x 64 38.9 vs 37.9 us, 1280x768 x 512 108.9 vs 102.6 us), so every group of the block is
+                // evaluated again per pixel and each sphere gets its own wave-wide flag
 #pragma nounroll
             for (int g = 0; g < kGroupsPerBlock; g++) {
                 const int gi = blk * kGroupsPerBlock + g;
@@ -716,7 +804,9 @@ __device__ __forceinline__ bool rc_shadow_blocks(const RcKernArgs &a, const floa
 #pragma unroll
                 for (int s = 0; s < kGroup; s++) {
                     const int j = gi * kGroup + s;
+                    RC_COUNT(6, 1);
                     if (cm[s] == 0ull || j >= cn) continue;
+                    RC_COUNT(7, 1);
                     RcExactSphere e;
                     if (s_exact) {
                         const float4 v = s_exact[j];
@@ -731,11 +821,12 @@ __device__ __forceinline__ bool rc_shadow_blocks(const RcKernArgs &a, const floa
                     }
                 }
             }
+            }
             if (FAST) {                            // large scenes only: at 64 spheres the check costs more than it saves
                 bool pending = false;              // a shadow ray of this lane still unoccluded (misses carry ldist = -1)
 #pragma unroll
                 for (int p = 0; p < P; p++) pending = pending || (ldist[p] >= 0.0f && !((shadowed >> p) & 1u));
-                if (__builtin_amdgcn_ballot_w64(pending) == 0ull) return true;
+                if (__builtin_amdgcn_ballot_w64(pending) == 0ull) { RC_COUNT(10, 1); return true; }
 #pragma unroll
                 for (int p = 0; p < P; p++)
                     if ((shadowed >> p) & 1u) flen[p] = __builtin_inff();
@@ -784,6 +875,7 @@ __device__ __forceinline__ void rc_shadow_pass(const RcKernArgs &a, char *lds,
 #pragma unroll
     for (int p = 0; p < P; p++) any_hit = any_hit || (idx[p] != -1);
     bool wave_has_hits = __builtin_amdgcn_ballot_w64(any_hit) != 0ull;   // no hit pixel: no shadow rays
+    if (wave_has_hits) RC_COUNT(9, 1);
 
     float cax = 0.0f, cay = 0.0f, caz = 0.0f, ccos = 1.0f, csin = 0.0f;
     bool cone_forced = (forced_mask != 0ull);
@@ -848,6 +940,26 @@ __device__ __forceinline__ void rc_shadow_pass(const RcKernArgs &a, char *lds,
                 }
             }
         }
+    }
+
+    // Dominant-axis form: interval bounds of this wave's filter inputs (u, v, threshold) over its shadow rays
+    RcShadowBounds wb = {0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f};
+    if (!CULL && SHFAST && fast_axis >= 0 && wave_has_hits) {
+        const float inf = __builtin_inff();
+        float lo1 = inf, hi1 = -inf, lo2 = inf, hi2 = -inf, tm = inf;
+#pragma unroll
+        for (int p = 0; p < P; p++) {
+            if (idx[p] != -1) {
+                lo1 = fminf(lo1, fu[p]); hi1 = fmaxf(hi1, fu[p]);
+                lo2 = fminf(lo2, fv[p]); hi2 = fmaxf(hi2, fv[p]);
+                tm = fminf(tm, flen[p]);
+            }
+        }
+        wb.lo1 = rc_wave_min(lo1); wb.hi1 = rc_wave_max(hi1);
+        wb.lo2 = rc_wave_min(lo2); wb.hi2 = rc_wave_max(hi2);
+        wb.abs1 = fmaxf(fabsf(wb.lo1), fabsf(wb.hi1));
+        wb.abs2 = fmaxf(fabsf(wb.lo2), fabsf(wb.hi2));
+        wb.thr_min = rc_wave_min(tm);
     }
 
     for (int base = 0; base < a.n; base += cap) {
@@ -933,10 +1045,10 @@ __device__ __forceinline__ void rc_shadow_pass(const RcKernArgs &a, char *lds,
         if (!CULL && nblocks > 0) {
             bool done;
             if (SHFAST && fast_axis >= 0)
-                done = rc_shadow_blocks<P, true>(a, s_rec, s_flag, s_exact, base, cn, nblocks, flag0_mask, forced_mask,
+                done = rc_shadow_blocks<P, true>(a, s_rec, s_flag, s_exact, base, cn, nblocks, flag0_mask, forced_mask, wb,
                                                  fu, fv, flen, ex, ey, ez, ldist, idx, shadowed);
             else
-                done = rc_shadow_blocks<P, false>(a, s_rec, s_flag, s_exact, base, cn, nblocks, flag0_mask, forced_mask,
+                done = rc_shadow_blocks<P, false>(a, s_rec, s_flag, s_exact, base, cn, nblocks, flag0_mask, forced_mask, wb,
                                                   fu, fv, flen, ex, ey, ez, ldist, idx, shadowed);
             if (done) wave_has_hits = false;       // later chunks: this wave only keeps the barriers
         }
@@ -970,6 +1082,7 @@ __device__ __forceinline__ void rc_tiled_body(const RcKernArgs &a, char *lds)
         // un-normalised q of kernel.cu:49.  EXT needs d for every pixel (plane test), the culled variant
         // its bounds at once.
         constexpr bool LAZY = !EXT && !CULL;
+        RC_COUNT(8, 1);
         const int tyi = blockIdx.y, txi = blockIdx.x;
         const int x0 = txi * (2 * TW) + (wave & 1) * TW + lx;
         const int row = tyi * 16 + (wave >> 1) * 8 + ly;
@@ -1188,6 +1301,7 @@ __device__ __forceinline__ void rc_tiled_body(const RcKernArgs &a, char *lds)
                 }
             } else
             for (int blk = 0; blk < nblocks; blk++) {
+                RC_COUNT(0, 1);
                 float m[P];
 #pragma unroll
                 for (int p = 0; p < P; p++) m[p] = -__builtin_inff();
@@ -1211,6 +1325,7 @@ __device__ __forceinline__ void rc_tiled_body(const RcKernArgs &a, char *lds)
 #pragma unroll
                 for (int p = 0; p < P; p++) flagged |= __builtin_amdgcn_ballot_w64(m[p] >= len[p]);
                 if (flagged != 0ull) {
+                    RC_COUNT(1, 1);
                     if (LAZY && !have_d) {             // first flagged block of this wave: see LAZY above
 #pragma unroll
                         for (int p = 0; p < P; p++) rc_normalise(dx[p], dy[p], dz[p]);
@@ -1266,12 +1381,18 @@ __device__ __forceinline__ void rc_tiled_body(const RcKernArgs &a, char *lds)
             }
         }
 
-        if (row < a.rows) {
+        // (EXT: the pixel's row and columns are formed again from an opaque copy of the thread index, so that
+        // the compiler does not carry them, sign-extended, across the shadow pass in registers it does not have)
+        int xs = x0, rows_ = row;
+        if (EXT) {
+            int t2 = threadIdx.x;
+            asm volatile("" : "+v"(t2));
+            xs = txi * (2 * TW) + ((t2 >> 6) & 1) * TW + (t2 & 7);
+            rows_ = tyi * 16 + (t2 >> 7) * 8 + ((t2 & 63) >> 3);
+        }
+        if (rows_ < a.rows) {
+            const int row = rows_;
             const RcRowPtr rowp = rc_row_ptr(a, row);
-            // (EXT: the opaque copy makes the compiler form the column indices again from x0 here instead of
-            // carrying them, sign-extended, across the shadow pass in registers it does not have)
-            int xs = x0;
-            if (EXT) asm volatile("" : "+v"(xs));
 #pragma unroll
             for (int p = 0; p < P; p++) {
                 const int x = xs + 8 * p;
@@ -1287,7 +1408,7 @@ __device__ __forceinline__ void rc_tiled_body(const RcKernArgs &a, char *lds)
                             if (SHFAST)
                                 rc_ray_dir(a, *(volatile const float *)(a.sin_x + x), *(volatile const float *)(a.sin_y + row + a.y_offset),
                                            rdx, rdy, rdz);
-                            rc_ext_shade(a, idx[p], minDist[p], rdx, rdy, rdz, (shadowed >> p) & 1u, ldist[p], r, g, b);
+                            rc_ext_shade(a, idx[p], minDist[p], rdx, rdy, rdz, (shadowed >> p) & 1u, (SHFAST && P >= 4) ? -1.0f : ldist[p], r, g, b);   // (128-register kernel: evaluated again rather than kept)
                         }
                     } else if (idx[p] >= 0) {
                         rc_shade(a, idx[p], minDist[p], dx[p], dy[p], dz[p], r, g, b);

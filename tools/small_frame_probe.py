@@ -17,7 +17,13 @@ lib = abi.load()
 e0, e1 = C.c_void_p(), C.c_void_p()
 lib.rc_event_create(C.byref(e0)); lib.rc_event_create(C.byref(e1))
 surf = DeviceBuffer(3840 * 16 * 2160)
-ext = abi.RcExt(**{k: (abi.RcVec3(*v) if isinstance(v, tuple) else v) for k, v in configs.DEFAULT_EXT.items()})
+def make_ext(**over):
+    return abi.RcExt(**{k: (abi.RcVec3(*v) if isinstance(v, tuple) else v) for k, v in dict(configs.DEFAULT_EXT, **over).items()})
+
+
+# shading names: ref, ext, and EXT with one feature off (where the EXT time goes)
+exts = {"ext": make_ext(), "ext_noshadow": make_ext(shadows=0), "ext_noplane": make_ext(has_plane=0),
+        "ext_nospec": make_ext(shininess_log2=0, specular=0.0)}
 variants = [("auto", abi.VARIANT_AUTO), ("P2", abi.VARIANT_TILED2), ("P4", abi.VARIANT_TILED4)]
 
 
@@ -51,11 +57,11 @@ for name in names:
             cells = []
             for vname, v in variants:
                 opts = abi.RcOpts(variant=v, tuning=tuning)
-                if shading == "ext":
-                    opts.mode = abi.MODE_EXT; opts.ext = C.pointer(ext)
+                if shading != "ref":
+                    opts.mode = abi.MODE_EXT; opts.ext = C.pointer(exts[shading])
                 big = w * h * max(n, 8) > 2e9
                 t = timed(screen, scene, opts, 400 if big else 6000, 200 if big else 2000)
                 cells.append(f"{vname} {t:8.2f} us")
-            print(f"{name:20s} n={n:5d} {shading}  " + "  ".join(cells), flush=True)
+            print(f"{name:20s} n={n:5d} {shading:12s}  " + "  ".join(cells), flush=True)
         for b in bufs:
             b.free()
