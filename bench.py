@@ -75,6 +75,11 @@ def parse():
                     help="only the headline measurement: no culled_variant / display_conversion legs (for profiling runs)")
     ap.add_argument("--tuning", type=int, default=0, help="rc_opts.tuning bits (RC_TUNE_*): launcher overrides for A/B runs")
     ap.add_argument("--no-cpu", action="store_true", help="skip the cpu_baseline leg")
+    ap.add_argument("--no-bands-check", action="store_true",
+                    help="with more than one rank in frames mode: skip the untimed bands_check leg (one 7680x4320 x 4096 frame "
+                         "through both row-band gathers, checked against the whole frame)")
+    ap.add_argument("--bands-check-timeout", type=float, default=240.0,
+                    help="seconds after which a stuck bands_check leg is abandoned: the headline line is printed without it")
     ap.add_argument("--no-clock-ramp", action="store_true",
                     help="do not extend the untimed warm-up until the GPU has reached its steady clock")
     ap.add_argument("--cpu-threads", type=int, default=0,
@@ -112,6 +117,8 @@ def self_launch(args):
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={args.gpus}",
            "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
     env = dict(os.environ)
+    # RCCL shares device buffers between the ranks' processes through dmabuf handles; the legacy IPC mode this
+    # switches off is not supported by the host driver here (hipIpcGetMemHandle fails with "invalid argument")
     env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
     proc = subprocess.run(cmd, env=env, stdout=subprocess.PIPE)
     lines = [ln for ln in proc.stdout.decode(errors="replace").splitlines() if ln.startswith("{")]
@@ -229,6 +236,137 @@ def pipelined_readback(lib, scene, base_opts, w, h, steps, warmup, what):
     lib.rc_stream_destroy(copy)
     return {"readback": what, "value": w * h * steps / dt / 1e6, "unit": "Mrays/s", "ms_per_frame": dt / steps * 1e3,
             "pcie_gbs": w * h * bpp * steps / dt / 1e9, "bytes_per_frame": w * h * bpp}
+
+
+def make_scene(cfg):
+    """Scene arrays of a workload resident in HBM (SceneManager.cpp:17-24) -> (RcScene, buffers to keep alive)."""
+    n = cfg["n"]
+    pos, rad, col = generate_scene(n, cfg["seed"])
+    bufs = []
+    for a in (pos, rad, col):
+        b = DeviceBuffer(max(a.nbytes, 4))
+        b.upload(a)
+        bufs.append(b)
+    scene = abi.RcScene()
+    scene.sphere_num = n
+    scene.position, scene.radius, scene.color = (b.ptr.value for b in bufs)
+    cam = Camera(cfg["width"], cfg["height"])
+    cam.position, cam.rotation = cfg["position"], cfg["rotation"]
+    scene.cam = cam.get_data()
+    return scene, bufs
+
+
+def bands_check(lib, torch, dist, world, rank, comm_device, stream, reps=3):
+    """With more than one rank, outside the timed headline: ONE frame of 7680x4320 x 4096 spheres cut into row
+    bands (two pieces per rank), rendered by all ranks and assembled on rank 0 -- once through
+    torch.distributed (sharding.BandGather) and once through librc_gather.so -- each checked bit for bit
+    against the frame rank 0 renders whole, with its time and every rank's render time.  The first run on a
+    multi-GPU node thereby exercises both gather paths whatever mode the headline used."""
+    cfg = configs.CONFIGS["c4_7680x4320_n4096"]
+    w, h = cfg["width"], cfg["height"]
+    parts = 2
+    scene, keep = make_scene(cfg)
+    g = sharding.BandGather(h, world, rank, parts=parts, layout="contiguous")
+    band = torch.empty((g.rows, w, 4), dtype=torch.float32, device="cuda")
+    full = torch.empty((h, w, 4), dtype=torch.float32, device="cuda") if rank == 0 else None
+    base = abi.RcOpts(full_height=h, stream=stream)
+
+    def render_piece(k):
+        sb, se = g.pieces[k]
+        if se <= sb:
+            return
+        piece = abi.RcScreen(band[g.offsets[k]:].data_ptr(), w, se - sb, w * 16)
+        o = abi.RcOpts.from_buffer_copy(bytes(base))
+        o.y_offset = sb
+        abi.check(lib.rc_render(C.byref(piece), C.byref(scene), C.byref(o)), "rc_render (bands_check)")
+
+    def fence():
+        dist.barrier()
+        torch.cuda.synchronize()
+
+    out = {"workload": "c4_7680x4320_n4096", "pieces_per_rank": parts, "band_layout": "contiguous",
+           "rows_of_this_run": [list(sharding.rank_pieces(h, world, r, parts)) for r in range(world)]}
+    # every rank's render alone (no exchange)
+    ev0, ev1 = C.c_void_p(), C.c_void_p()
+    abi.check(lib.rc_event_create(C.byref(ev0)))
+    abi.check(lib.rc_event_create(C.byref(ev1)))
+    for k in range(parts):
+        render_piece(k)
+    fence()
+    abi.check(lib.rc_event_record(ev0, stream))
+    for _ in range(reps):
+        for k in range(parts):
+            render_piece(k)
+    abi.check(lib.rc_event_record(ev1, stream))
+    fence()
+    ms = C.c_float()
+    abi.check(lib.rc_event_elapsed_ms(ev0, ev1, C.byref(ms)))
+    out["per_rank_render_ms"] = sharding.gather_floats(ms.value / reps, comm_device)
+
+    whole = None
+    if rank == 0:
+        whole = torch.empty((h, w, 4), dtype=torch.float32, device="cuda")
+        ws = abi.RcScreen(whole.data_ptr(), w, h, w * 16)
+        abi.check(lib.rc_render(C.byref(ws), C.byref(scene), C.byref(base)), "rc_render (whole)")
+        torch.cuda.synchronize()
+
+    def torch_frame():
+        if comm_device == "cuda":
+            g.post_receives(full)
+            for k in range(parts):
+                render_piece(k)
+                g.piece_rendered(k, band, full)
+            g.wait()
+        else:                                   # rehearsal backend: the same exchange staged through host memory
+            for k in range(parts):
+                render_piece(k)
+            torch.cuda.current_stream().synchronize()
+            host_band = band.cpu()
+            host_full = torch.empty(full.shape, dtype=full.dtype) if rank == 0 else None
+            g.post_receives(host_full)
+            for k in range(parts):
+                g.piece_rendered(k, host_band, host_full)
+            g.wait()
+            if rank == 0:
+                full.copy_(host_full)
+
+    def run(frame_fn):
+        if rank == 0:
+            full.zero_()
+        frame_fn()                               # warm-up, and the frame that is checked
+        fence()
+        ok = bool(torch.equal(full, whole)) if rank == 0 else None
+        t0 = time.perf_counter()
+        for _ in range(reps):
+            frame_fn()
+        fence()
+        dt = sharding.max_over_ranks(time.perf_counter() - t0, comm_device) / reps
+        return {"frame_ms": dt * 1e3, "gather_check": ok, "value": w * h / dt / 1e6, "unit": "Mrays/s"}
+
+    out["torch"] = run(torch_frame)
+    if comm_device == "cuda":
+        from cudaraytracing_amd import gather as rcg
+        ident = [rcg.unique_id() if rank == 0 else None]
+        dist.broadcast_object_list(ident, src=0)
+        cg = rcg.Gather(world, rank, ident[0])
+        full_ptr = full.data_ptr() if full is not None else None
+
+        def c_frame():
+            cg.begin(parts, full_ptr, w * 16, h, stream)
+            for k in range(parts):
+                render_piece(k)
+                cg.piece(k, parts, band.data_ptr(), full_ptr, w * 16, h, stream)
+            cg.wait(stream)
+
+        out["c"] = run(c_frame)
+        cg.destroy()
+    else:
+        out["c"] = {"skipped": "librc_gather.so needs RCCL; this run used the %s rehearsal backend" % comm_device}
+    lib.rc_event_destroy(ev0)
+    lib.rc_event_destroy(ev1)
+    for b in keep:
+        b.free()
+    return out
 
 
 def main():
@@ -371,6 +509,7 @@ def main():
             # event on ours, so piece k travels while piece k + 1 renders.  Every rank makes the same calls;
             # a band shorter than `subbands` rows has empty pieces.
             row_bytes = w * (4 if gather8 else 16)
+            cgather.begin(args.subbands, full.data_ptr() if full is not None else None, row_bytes, h, stream)
             for k in range(args.subbands):
                 if k < len(gatherer.pieces):
                     render_piece(k)
@@ -494,6 +633,12 @@ def main():
         # records built once per frame in a caller workspace (16 bytes per sphere); below ~1000
         # spheres the extra launch costs more than every workgroup building its own
         use_ws = n >= 1024
+        culled_counters = None
+        try:
+            with open(os.path.join(ROOT, "profiles", "counters.json")) as f:
+                culled_counters = json.load(f).get("%s|%s|culled" % (args.config, args.shading))
+        except (OSError, ValueError):
+            pass
         if use_ws:       # records + per-bin sphere lists
             wsp = torch.empty((lib.rc_workspace_bytes_frame(n, w, rows) + 3) // 4, dtype=torch.float32, device="cuda")
             copts.workspace, copts.workspace_bytes = wsp.data_ptr(), wsp.numel() * 4
@@ -512,8 +657,11 @@ def main():
                              + ("records and per-bin sphere lists built once per frame in rc_opts.workspace; " if use_ws else "") +
                              "bit-identical surfaces, not one test per (pixel, sphere) pair",
                   "value": w * h / (cms * 1e-3) / 1e6, "unit": "Mrays/s", "frame_ms": cms,
-                  "roofline": {"bound": "hbm", "achieved": 16.0 * w * h / (cms * 1e-3) / 1e9, "peak": HBM_PEAK_GBS,
-                               "unit": "GB/s", "frac": 16.0 * w * h / (cms * 1e-3) / 1e9 / HBM_PEAK_GBS}}
+                  # no roofline block: the variant is instruction-bound (VALU busy in profiles/counters.json under
+                  # "<config>|<shading>|culled"), not HBM-bound, and it does not run one test per (pixel, sphere) pair,
+                  # so neither of the line's rooflines prices it; the write rate is given for scale only
+                  "hbm_write_gbs": 16.0 * w * h / (cms * 1e-3) / 1e9,
+                  "valu_busy": (culled_counters or {}).get("valu_busy"), "counters_source": (culled_counters or {}).get("source")}
 
     # Secondary measurement (N=1): the display step after the path, float RGBA -> R8G8B8A8
     # (DXManager.cpp:134,299,328), standalone (rc_to_rgba8: 16 B read + 4 B written per pixel,
@@ -541,8 +689,11 @@ def main():
         gbs = 20.0 * w * rows / (conv_ms * 1e-3) / 1e9
         display = {"kernel": "rc_rgba8_kernel", "standalone_ms": conv_ms, "bytes_per_pixel": 20,
                    "roofline": {"bound": "hbm", "achieved": gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": gbs / HBM_PEAK_GBS},
-                   "note": "back-to-back launches on one frame: a 3840x2160 float surface (133 MB) stays in the 256 MB "
-                           "Infinity Cache, so the achieved rate is a cache-assisted figure, not raw HBM",
+                   "note": ("back-to-back launches on one frame: the %dx%d float surface (%.0f MB) %s the 256 MiB Infinity Cache, "
+                            "so the achieved rate is %s" % (
+                                w, rows, 16.0 * w * rows / 1e6,
+                                "fits" if 20 * w * rows <= 256 * 2 ** 20 else "does not fit",
+                                "a cache-assisted figure, not raw HBM" if 20 * w * rows <= 256 * 2 ** 20 else "an HBM figure")),
                    "fused_frame_ms": fused_ms, "fused_extra_ms": fused_ms - ev_ms.value / args.steps}
 
     # Secondary measurement (--graph, N=1): the same K steps captured into ONE HIP graph and replayed
@@ -594,12 +745,20 @@ def main():
     value = w * h * frames_total / dt_max / 1e6
     kernel_ms = ev_ms.value / args.steps           # HIP events on the launch stream, this rank
     tests = w * rows * n
-    shadow_tests = 0
+    shadow_tests = 0                 # algorithmic: one shadow ray per hit pixel, tested against every sphere
+    shadow_tests_executed = None     # what the shadow loop actually ran (instrumented build, tools/count_tests.py)
+    executed_source = None
     if args.shading == "ext":
-        # one shadow ray per hit pixel, tested against every sphere: 16 FLOP per test (per-ray
-        # origin form); hit pixels counted on the rendered frame
-        hit_pixels = int((frame[..., :3] != 0).any(dim=-1).sum().item())
+        hit_pixels = int((frame[..., :3] != 0).any(dim=-1).sum().item())   # counted on the rendered frame
         shadow_tests = hit_pixels * n
+        try:
+            with open(os.path.join(ROOT, "profiles", "executed_tests.json")) as f:
+                ex = json.load(f).get("%s|ext" % args.config)
+            if ex and args.variant == "tiled" and rows == h and not args.sequence and args.tuning == 0:
+                shadow_tests_executed = int(ex["shadow_tests_executed"])
+                executed_source = "profiles/executed_tests.json"
+        except (OSError, ValueError, KeyError):
+            pass
     # Floating-point work the kernel EXECUTES per test.  Tiled kernel, primary rays: the separable
     # filter T = fma(a_pixel, beta, r), r = fma(b_row, gamma, alpha) shared by the lane's P pixels,
     # then one input of the running maximum: (1 + 1/P) FMA (2 FLOP each) + 1.  Shadow rays (EXT,
@@ -609,10 +768,7 @@ def main():
     # Literal kernel: kernel.cu:53-58 as written, 21 FLOP to the discriminant.
     cu_count = C.c_int()
     abi.check(lib.rc_device_info(local_rank, C.byref(cu_count), None, None))
-    tiles = lambda p: -(-w // (16 * p)) * -(-rows // 16)       # noqa: E731  (the launcher's own rule)
-    want = 5 * cu_count.value
-    want4 = 2 * want if (args.shading == "ext" and args.variant != "culled" and n < 2048) else want
-    ppl = 8 if (args.shading == "ref" and args.variant != "culled" and tiles(8) >= want) else (4 if tiles(4) >= want4 else 2)
+    ppl = configs.pixels_per_lane(w, rows, n, args.shading == "ext", args.variant == "culled", cu_count.value)
     ppl = {"tiled2": 2, "tiled4": 4, "tiled8": 8 if args.shading == "ref" else 4}.get(args.variant, ppl)
     axis = False
     if args.variant == "literal":
@@ -622,7 +778,11 @@ def main():
         axis = (args.tuning & abi.TUNE_SHADOW_AXIS_ON) or (n >= 1024 and not (args.tuning & abi.TUNE_SHADOW_AXIS_OFF))
         executed_flop, executed_shadow_flop = 2.0 * (1.0 + 1.0 / ppl) + 1.0, (5.0 if axis else 6.0)
     secs = kernel_ms * 1e-3
-    executed_tflops = (executed_flop * tests + executed_shadow_flop * shadow_tests) / secs / 1e12
+    # EXT: the shadow loop is priced with the tests it EXECUTED where the instrumented build has counted them for
+    # this workload (whole waves of every block run: idle lanes and padding included, early exits excluded);
+    # otherwise with the algorithmic count, which overstates it when the any-hit exit leaves the loop early
+    priced_shadow_tests = shadow_tests_executed if shadow_tests_executed is not None else shadow_tests
+    executed_tflops = (executed_flop * tests + executed_shadow_flop * priced_shadow_tests) / secs / 1e12
     # counter-derived figures of this exact workload / shading / variant, if tools/profile.sh has been
     # run for it (separate rocprofv3 --pmc passes; summary committed under profiles/)
     counters = None
@@ -635,6 +795,7 @@ def main():
         counters = None                                         # measured on the whole static frame only
     traffic = (counters["hbm_write_bytes"] + counters["hbm_read_bytes"]) if counters else None
 
+    out = None
     if rank == 0:
         cu, khz = C.c_int(), C.c_int()
         abi.check(lib.rc_device_info(local_rank, C.byref(cu), C.byref(khz), None))
@@ -655,12 +816,12 @@ def main():
                        "device": name.value.decode(), "compute_units": cu.value, "clock_mhz": khz.value / 1e3},
             "frame_ms": kernel_ms, "frame_ms_stats": frame_stats, "per_rank_step_ms": per_rank_ms, "gather_check": gather_check,
             "roofline": {
-                # The contract knows two rooflines, hbm | mfma; this kernel belongs to neither name: it
-                # issues NO MFMA and is bound by the FP32 vector ALU (VALU) issue rate.  `peak` is the
-                # FP32 vector peak (which equals the dense f32 matrix peak, 157.3 TFLOP/s).
-                "bound": "valu", "bound_detail": "compute roofline = FP32 vector ALU issue (the contract's 'mfma' "
-                                                 "slot; no MFMA instruction is used; f32 vector peak = dense f32 "
-                                                 "MFMA peak = 157.3 TFLOP/s at 2.4 GHz)",
+                # The contract knows two rooflines, hbm | mfma.  This kernel is compute-bound, so it goes in the
+                # compute ("mfma") slot, although it issues NO MFMA: what bounds it is the FP32 vector ALU
+                # (VALU) issue rate.  `peak` is the FP32 vector peak (= the dense f32 matrix peak, 157.3 TFLOP/s).
+                "bound": "mfma", "bound_detail": "compute-bound: the contract's compute slot is named 'mfma', but this kernel "
+                                                 "issues NO MFMA instruction; it is bound by FP32 vector-ALU (VALU) issue, and "
+                                                 "`peak` is the f32 vector peak (= the dense f32 matrix peak, 157.3 TFLOP/s at 2.4 GHz)",
                 "achieved": executed_tflops, "peak": FP32_VECTOR_PEAK_TFLOPS, "unit": "TFLOP/s",
                 "frac": executed_tflops / FP32_VECTOR_PEAK_TFLOPS,
                 "frac_basis": "FLOP the kernel executes in its inner loops (executed_flop_per_test x tests_per_launch"
@@ -674,12 +835,17 @@ def main():
                 "counters_source": counters.get("source") if counters else None,
                 "pixels_per_lane": None if args.variant == "literal" else ppl,
                 "executed_flop_per_test": executed_flop, "executed_flop_per_shadow_test": executed_shadow_flop if shadow_tests else None,
-                "kernel": ("rc_draw_tiled<%d,%s,false>" % (ppl, "true" if args.shading == "ext" else "false"))
+                # template arguments: pixels per lane, EXT, CULL, BINS, SHFAST (dominant-axis shadow filter)
+                "kernel": ("rc_draw_tiled<%d, %s, false, false, %s>" % (ppl, "true" if args.shading == "ext" else "false",
+                                                                        "true" if (args.shading == "ext" and axis) else "false"))
                           if args.variant.startswith("tiled") else args.variant,
                 "kernel_ms": kernel_ms, "tests_per_launch": tests, "shadow_tests_per_launch": shadow_tests,
-                "shadow_tests_note": ("hit pixels x spheres (the algorithmic count); from 1024 spheres the shadow loop leaves "
-                                      "early for waves whose shadow rays are all occluded, so fewer are executed and frac is "
-                                      "an upper bound of the executed fraction in EXT mode") if (shadow_tests and axis) else None,
+                "shadow_tests_executed_per_launch": shadow_tests_executed, "shadow_tests_executed_source": executed_source,
+                "shadow_tests_note": (("frac prices the shadow loop with the tests it executed (counted by the instrumented build)"
+                                       if shadow_tests_executed is not None else
+                                       "frac prices the shadow loop with hit pixels x spheres, the algorithmic count: an upper bound "
+                                       "of the executed work where the any-hit exit leaves the loop early (no executed count on file "
+                                       "for this workload)") if shadow_tests else None),
                 "tests_per_second": tests / secs,
                 # equivalent rates for comparisons, NOT roofline fractions: the same tests priced at the hoisted
                 # 7-FLOP form of kernel.cu:53-58 and at the 21 FLOP the reference (and the CPU baseline) execute
@@ -701,8 +867,35 @@ def main():
             out["gpu_over_cpu"] = value / out["cpu_baseline"]["value"]
         else:
             out["cpu_baseline"] = None
-        sys.stdout.flush()
-        os.write(result_fd, (json.dumps(out) + "\n").encode())
+
+    def emit():
+        if rank == 0:
+            sys.stdout.flush()
+            os.write(result_fd, (json.dumps(out) + "\n").encode())
+
+    # More than one rank, default (frames) mode: the headline above exchanged nothing on the data path, so both
+    # row-band gathers are exercised here, untimed by the headline.  A watchdog abandons the leg if a rank is stuck
+    # in it (the line is then printed without it and every rank leaves at once).
+    if world > 1 and args.mode == "frames" and not args.no_bands_check and not args.no_extras:
+        import threading
+
+        def abandon():
+            if rank == 0:
+                out["bands_check"] = {"error": "abandoned after %.0f s" % args.bands_check_timeout}
+                emit()
+            os._exit(0)
+
+        dog = threading.Timer(args.bands_check_timeout, abandon)
+        dog.daemon = True
+        dog.start()
+        try:
+            res = bands_check(lib, torch, dist, world, rank, comm_device, stream)
+        except Exception as e:                   # noqa: BLE001  (reported in the line; the headline stands)
+            res = {"error": repr(e)}
+        dog.cancel()
+        if rank == 0:
+            out["bands_check"] = res
+    emit()
 
     if cgather is not None:
         cgather.destroy()

@@ -61,6 +61,18 @@ def build(force=False, verbose=False):
         finally:
             if os.path.exists(tmp):
                 os.remove(tmp)
+    cli_src = os.path.join(CSRC, "host", "rc_render_main.cpp")
+    cli_deps = [cli_src, LIB_PATH] + [
+        os.path.join(CSRC, "host", h) for h in ("rc_camera.hpp", "rc_scene_manager.hpp", "rc_raycaster.hpp", "rc_frame_pipeline.hpp")
+    ]
+    if os.path.exists(cli_src) and (force or _stale(CLI_PATH, cli_deps)):
+        cmd = ["g++", "-O2", "-std=c++17", "-ffp-contract=off", "-I" + os.path.join(_ROOT, "include"),
+               "-I" + os.path.join(CSRC, "host"), cli_src, "-o", CLI_PATH,
+               "-L" + _HERE, "-lrc_hip", "-Wl,-rpath,$ORIGIN", "-lpthread"]
+        if verbose:
+            print(" ".join(cmd))
+        subprocess.run(cmd, check=True, cwd=_ROOT)
+    # last: the optional RCCL band-gather library
     gather_deps = [GATHER_SRC, os.path.join(_ROOT, "include", "rc_gather.h")]
     if force or _stale(GATHER_PATH, gather_deps):
         if os.path.exists(GATHER_PATH):
@@ -74,20 +86,13 @@ def build(force=False, verbose=False):
         try:
             subprocess.run(cmd, check=True, cwd=_ROOT)
             os.replace(GATHER_PATH + ".tmp", GATHER_PATH)
+        except subprocess.CalledProcessError as e:
+            # the band gather is optional (gather.load() reports a missing library): a failed RCCL link must not
+            # take the core library and the CLI, already built above, down with it
+            print(f"warning: librc_gather.so was not built ({e}); --gather-impl c will be unavailable")
         finally:
             if os.path.exists(GATHER_PATH + ".tmp"):
                 os.remove(GATHER_PATH + ".tmp")
-    cli_src = os.path.join(CSRC, "host", "rc_render_main.cpp")
-    cli_deps = [cli_src, LIB_PATH] + [
-        os.path.join(CSRC, "host", h) for h in ("rc_camera.hpp", "rc_scene_manager.hpp", "rc_raycaster.hpp", "rc_frame_pipeline.hpp")
-    ]
-    if os.path.exists(cli_src) and (force or _stale(CLI_PATH, cli_deps)):
-        cmd = ["g++", "-O2", "-std=c++17", "-ffp-contract=off", "-I" + os.path.join(_ROOT, "include"),
-               "-I" + os.path.join(CSRC, "host"), cli_src, "-o", CLI_PATH,
-               "-L" + _HERE, "-lrc_hip", "-Wl,-rpath,$ORIGIN", "-lpthread"]
-        if verbose:
-            print(" ".join(cmd))
-        subprocess.run(cmd, check=True, cwd=_ROOT)
     return LIB_PATH
 
 

@@ -58,3 +58,14 @@ def band_rows(height, world, rank):
     base, rem = divmod(height, world)
     begin = rank * base + min(rank, rem)
     return begin, begin + base + (1 if rank < rem else 0)
+
+
+def pixels_per_lane(width, rows, n, ext, culled, compute_units):
+    """Pixels per lane the library's launcher picks for a frame (the rule of rc_launch_draw in csrc/rc_kernels.hip,
+    restated for bench.py and the tools, which price the executed work per test with it)."""
+    tiles = lambda p: -(-width // (16 * p)) * -(-rows // 16)   # noqa: E731
+    want = 5 * compute_units
+    if not ext and not culled and tiles(8) >= 9 * compute_units:
+        return 8
+    want4 = 2 * want if (ext and not culled and n < 2048) else want
+    return 4 if tiles(4) >= want4 else 2

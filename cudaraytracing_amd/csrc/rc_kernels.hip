@@ -1630,12 +1630,15 @@ hipError_t rc_launch_draw(const RcKernArgs &a, int variant, int compute_units, h
     if (variant == RC_KVARIANT_TILED4) return rc_launch_tiled<4>(a, stream);
     if (variant == RC_KVARIANT_TILED8) return a.ext_mode ? rc_launch_tiled<4>(a, stream) : rc_launch_tiled<8>(a, stream);
     // Automatic: more pixels per lane share more of the per-sphere work, but the frame must
-    // still cut into enough workgroups to fill the chip (>= 5 per CU; measured crossovers:
-    // 1280x768 -> 2, 1920x1080 -> 4, 3840x2160 and up -> 8 pixels per lane).
+    // still cut into enough workgroups to fill the chip: >= 5 per CU for 4 pixels per lane, >= 9 per CU for 8
+    // (tools/p_sweep.py, 8 formats x 5 sphere counts: 1280x768 -> 2, 1920x1080 -> 4, 3840x2160 and up -> 8;
+    // with 7-8 workgroups per CU -- 2560x1440, 3840x1080, a 7680x540 band -- 8 pixels per lane win by at most
+    // 1.5 % at 1024 spheres and more, and lose 3-20 % below that and 8-16 % on the band).
     const long long want = 5LL * compute_units;
+    const long long want8 = 9LL * compute_units;
     // EXT keeps shadow-ray state per pixel: at most 4 pixels per lane.  The culled variant
     // prefers small wave tiles (fewer pixels share a visited sphere): 4 at most as well.
-    if (!a.ext_mode && !a.cull && rc_tile_count<8>(a) >= want) return rc_launch_tiled<8>(a, stream);
+    if (!a.ext_mode && !a.cull && rc_tile_count<8>(a) >= want8) return rc_launch_tiled<8>(a, stream);
     // EXT below 2048 spheres: 4 pixels per lane pay only from 10 workgroups per CU (tools/p_sweep.py, 1920x1080:
     // 2 pixels per lane 2 % faster at 64 spheres, 6 % at 256, 5 % at 1024, but 5 % slower at 4096; at
     // 2560x1440 4 pixels per lane win at every count).

@@ -15,6 +15,7 @@ SYMBOLS = {
     "rc_sub_band": (None, [C.c_int, C.c_int, C.c_int, C.c_int, C.POINTER(C.c_int), C.POINTER(C.c_int)]),
     "rc_gather_unique_id": (C.c_int, [C.c_void_p]),
     "rc_gather_create": (C.c_int, [C.POINTER(C.c_void_p), C.c_int, C.c_int, C.c_void_p]),
+    "rc_gather_begin": (C.c_int, [C.c_void_p, C.c_int, C.c_void_p, C.c_size_t, C.c_int, C.c_void_p]),
     "rc_gather_piece": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_size_t, C.c_int, C.c_void_p]),
     "rc_gather_wait": (C.c_int, [C.c_void_p, C.c_void_p]),
     "rc_gather_destroy": (C.c_int, [C.c_void_p]),
@@ -74,6 +75,9 @@ class Gather:
         self.handle = C.c_void_p()
         keep = C.create_string_buffer(ident, ID_BYTES)
         check(self.lib.rc_gather_create(C.byref(self.handle), world, rank, keep), "rc_gather_create")
+
+    def begin(self, parts, full_ptr, row_bytes, height, stream):
+        check(self.lib.rc_gather_begin(self.handle, parts, full_ptr, row_bytes, height, stream), "rc_gather_begin")
 
     def piece(self, k, parts, band_ptr, full_ptr, row_bytes, height, stream):
         check(self.lib.rc_gather_piece(self.handle, k, parts, band_ptr, full_ptr, row_bytes, height, stream), "rc_gather_piece")

@@ -12,6 +12,9 @@
  * A band may be rendered and sent in `parts` pieces: the transfer of piece k runs on the library's own
  * stream behind an event recorded on the caller's stream, so it travels while piece k+1 renders.
  *
+ * Status: the exchange between two or more ranks has not run on hardware yet (the build had one GPU per box);
+ * with one rank, where the assembly is a device-to-device copy, it has (tests/test_parity_gpu.py).
+ *
  * Conventions as in rc_abi.h: 0 on success, negative on failure (-(hipError_t), RC_GATHER_ERCCL - the
  * ncclResult_t, or RC_GATHER_EINVAL); never exits, never throws; rc_gather_last_error() describes the
  * calling thread's last failure.  The library links librccl; librc_hip.so does not.
@@ -44,6 +47,12 @@ int rc_gather_unique_id(void *id);
 /* Joins the communicator on the CURRENT device (ncclCommInitRank: blocks until all `world` ranks have
  * called it).  world == 1 is allowed: the assembly is then a device-to-device copy. */
 int rc_gather_create(rc_gather **g, int world, int rank, const void *id);
+/* Optional, once per frame BEFORE the frame's renders are enqueued: rank 0 posts the receives of all `parts`
+ * pieces of every peer now, ordered only behind the work already on `stream` (whatever still reads the previous
+ * contents of `full`), so the peers' rows arrive while rank 0 renders its own band.  Without this call rank 0
+ * posts the receives of piece k inside rc_gather_piece(k), behind its own render of that piece.  No-op on the
+ * other ranks and with one rank.  The same parts / height / row_bytes as the rc_gather_piece calls that follow. */
+int rc_gather_begin(rc_gather *g, int parts, void *full, size_t row_bytes, int height, void *stream);
 /* Piece k of this rank's band goes to its rows of the full frame on rank 0.
  *   band       this rank's band: rows rc_band_rows(height, world, rank), contiguous, row_bytes each (DEVICE)
  *   full       rank 0: the whole frame, height x row_bytes, contiguous (DEVICE); ignored on other ranks

@@ -915,6 +915,15 @@ def test_bench_two_ranks_share_one_gpu(mode, extra, launcher):
     assert d["scaling"] == ("strong" if mode == "bands" else "weak")
     if mode == "bands":
         assert d["gather_check"] is True
+    else:
+        # frames mode exchanges nothing on the data path, so the line carries the untimed bands_check leg: one
+        # 7680x4320 x 4096 frame cut into row bands, gathered on rank 0 and compared with the whole frame
+        bc = d["bands_check"]
+        assert "error" not in bc, bc
+        assert bc["workload"] == "c4_7680x4320_n4096" and len(bc["per_rank_render_ms"]) == 2
+        assert bc["rows_of_this_run"] == [[[0, 1080], [1080, 2160]], [[2160, 3240], [3240, 4320]]]
+        assert bc["torch"]["gather_check"] is True and bc["torch"]["frame_ms"] > 0
+        assert "skipped" in bc["c"]                      # librc_gather.so needs RCCL, this rehearsal runs on gloo
 
 
 @pytest.mark.parametrize("extra", [[], ["--gather", "rgba8", "--subbands", "3"], ["--gather-impl", "c"],

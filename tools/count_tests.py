@@ -34,14 +34,6 @@ cu = C.c_int()
 abi.check(lib.rc_device_info(0, C.byref(cu), None, None))
 
 
-def pixels_per_lane(w, h, n, ext):
-    tiles = lambda p: -(-w // (16 * p)) * -(-h // 16)   # noqa: E731  (rc_launch_draw's rule)
-    want = 5 * cu.value
-    if not ext and tiles(8) >= want:
-        return 8
-    return 4 if tiles(4) >= (2 * want if (ext and n < 2048) else want) else 2
-
-
 result = {}
 surf = DeviceBuffer(7680 * 16 * 4320)
 for name, cfg in configs.CONFIGS.items():
@@ -66,7 +58,7 @@ for name, cfg in configs.CONFIGS.items():
         abi.check(lib.rc_render(C.byref(screen), C.byref(scene), C.byref(opts)))
         abi.check(lib.rc_sync(None))
         assert lib.rc_counters_fetch(C.byref(c), 1) == 0
-        p = pixels_per_lane(w, h, n, shading == "ext")
+        p = configs.pixels_per_lane(w, h, n, shading == "ext", False, cu.value)
         per_block = 32 * 64 * p                      # (pixel, sphere) pairs one wave evaluates per block
         r = {"pixels_per_lane": p, "waves": c[8], "tests_algorithmic": w * h * n,
              "primary_tests_executed": c[0] * per_block, "primary_blocks": c[0], "primary_blocks_flagged": c[1],
