@@ -16,7 +16,8 @@ GATHER_PATH = os.path.join(_HERE, "librc_gather.so")      # row-band assembly ov
 GATHER_SRC = os.path.join(CSRC, "rc_gather.cpp")
 
 SOURCES = [os.path.join(CSRC, "rc_kernels.hip"), os.path.join(CSRC, "rc_host.hip")]
-HEADERS = [os.path.join(CSRC, "rc_kernels.h"), os.path.join(_ROOT, "include", "rc_abi.h")] + [
+HEADERS = [os.path.join(CSRC, "rc_kernels.h"), os.path.join(_ROOT, "include", "rc_abi.h"),
+           os.path.join(_ROOT, "include", "rc_dropin.hpp")] + [
     os.path.join(CSRC, "host", h) for h in ("rc_camera.hpp", "rc_scene_manager.hpp", "rc_raycaster.hpp")]
 
 # -ffp-contract=off: every product/sum of the exact path is a separately rounded binary32

@@ -17,6 +17,7 @@
 #include <vector>
 
 #include "rc_abi.h"
+#include "rc_dropin.hpp"
 #include "rc_kernels.h"
 
 #pragma clang fp contract(off)
@@ -372,6 +373,7 @@ struct StaticScratch {
     bool loaded = false;               // tables of (fov_bits, width, full_height) are in ptr[0, 4 (width + full_height))
     uint32_t fov_bits = 0;
     int width = 0, full_height = 0;
+    bool captured = false;             // a call was recorded into a graph with these tables: they must never change again
 };
 StaticScratch g_static[kStaticDevices];
 float g_static_stage[kStaticDevices][kStaticTableFloats];   // host side of the table upload, one per device
@@ -406,13 +408,22 @@ extern "C" int rc_render_static(const rc_screen *screen, const rc_scene *scene, 
     hipStream_t stream = static_cast<hipStream_t>(o.stream);
     uint32_t fb;
     memcpy(&fb, &scene->cam.fov, 4);
+    hipStreamCaptureStatus cs = hipStreamCaptureStatusNone;
+    const bool capturing = stream && hipStreamIsCapturing(stream, &cs) == hipSuccess && cs == hipStreamCaptureStatusActive;
     if (!st.loaded || st.fov_bits != fb || st.width != screen->width || st.full_height != full_height) {
         // New frame format: tabulate on the host (kernel.cu:46-47, libm sinf) and upload on the caller's
         // stream, behind the frames already enqueued there that read the previous tables.  The wait makes
         // the staging array free for the next format change, whichever stream that comes from.
-        hipStreamCaptureStatus cs = hipStreamCaptureStatusNone;
-        if (stream && hipStreamIsCapturing(stream, &cs) == hipSuccess && cs == hipStreamCaptureStatusActive)
+        if (capturing)
             return rc_fail_arg("rc_render_static: this frame format is not loaded; render one frame of it before capturing");
+        // A graph that recorded a call replays it at any later time with the tables' address, not their
+        // contents: once a format has been captured it stays the only one this entry point serves on the GPU.
+        if (st.captured) {
+            snprintf(g_err, sizeof(g_err), "rc_render_static: a captured graph on device %d uses the tables of %dx%d; "
+                     "another frame format would overwrite them under it (use rc_render for other formats)",
+                     dev, st.width, st.full_height);
+            return RC_EINVAL;
+        }
         const float fov = scene->cam.fov;
         const int width = screen->width;
         float *h = g_static_stage[dev];
@@ -428,6 +439,7 @@ extern "C" int rc_render_static(const rc_screen *screen, const rc_scene *scene, 
         st.width = width;
         st.full_height = full_height;
     }
+    if (capturing) st.captured = true;
     const float *sx = reinterpret_cast<const float *>(st.ptr);
     void *records = (o.variant == RC_VARIANT_CULLED) ? st.ptr + kStaticTableBytes : nullptr;
     // exactly the records' size: the per-bin lists of the culled variant are not kept in the static array
@@ -476,21 +488,11 @@ extern "C" int rc_to_rgba8(const rc_screen *screen, void *rgba8, size_t rgba8_pi
 }
 
 // ---- source-level drop-in ------------------------------------------------------------------
-// Layout- and calling-convention-identical stand-ins for the reference's argument classes:
-// the copy constructor is user-provided exactly as at vec3.h:13-18, which makes Scene
-// non-trivial for the purposes of calls (passed by invisible reference), while Screen
-// (Screen.h:3-9) stays a trivially copyable 24-byte aggregate passed in memory.
-namespace rc_ref_abi {
-struct Vec3 {
-    float x, y, z;
-    Vec3() : x(0), y(0), z(0) {}
-    Vec3(const Vec3 &u) { x = u.x; y = u.y; z = u.z; }
-};
-struct CameraData { float aspect, fov; Vec3 position, forward, up, right; };
-struct Scene { int sphere_num; Vec3 *position; float *radius; Vec3 *color; CameraData cam; };
-struct Screen { void *surface; int width; int height; size_t pitch; };
-static_assert(sizeof(Scene) == sizeof(rc_scene) && sizeof(Screen) == sizeof(rc_screen), "drop-in layout");
-} // namespace rc_ref_abi
+// include/rc_dropin.hpp declares layout- and calling-convention-identical stand-ins for the reference's argument
+// classes: the copy constructor of Vec3 is user-provided exactly as at vec3.h:13-18, which makes Scene
+// non-trivial for the purposes of calls (passed by invisible reference), while Screen (Screen.h:3-9) stays a
+// trivially copyable 24-byte aggregate passed in memory.
+static_assert(sizeof(rc_ref_abi::Scene) == sizeof(rc_scene) && sizeof(rc_ref_abi::Screen) == sizeof(rc_screen), "drop-in layout");
 
 // kernel.cu:114-131.  void return; a failed launch only prints (kernel.cu:127-130).
 extern "C" void execute_kernel(rc_ref_abi::Screen screen, rc_ref_abi::Scene scene)

@@ -695,7 +695,7 @@ __device__ __forceinline__ bool rc_shadow_blocks(const RcKernArgs &a, const floa
         float m[P];
 #pragma unroll
         for (int p = 0; p < P; p++) m[p] = FAST ? -__builtin_inff() : 0.0f;
-#pragma unroll 4   // of 8: deeper unrolling prefetches more records than 128 VGPRs hold (spills, measured slower)
+#pragma unroll (P <= 2 ? 2 : 4)   // of 8: deeper unrolling prefetches more records than the register budget holds (spills, measured slower)
         for (int g = 0; g < kGroupsPerBlock; g++) {
             const float4 H0 = s_rec[(blk * kGroupsPerBlock + g) * 3 + 0];
             const float4 H1 = s_rec[(blk * kGroupsPerBlock + g) * 3 + 1];
@@ -1423,8 +1423,13 @@ __device__ __forceinline__ void rc_tiled_body(const RcKernArgs &a, char *lds)
 } // namespace
 
 // SHFAST (EXT, brute-force shadows only): the shadow pass may use the dominant-axis form of its filter.
+// Waves per SIMD the register budget is cut for: 4 for the 8-pixel REF and the 4-pixel EXT kernels (128
+// registers); 6 / 5 for the 2-pixel EXT kernels (80 / 96 registers, no spills), whose flagged-block path is a
+// chain of dependent LDS reads and scalar masks that more resident waves hide (measured 1920x1080 x 64 38.1 ->
+// 36.0 us, 1280x768 x 512 104.0 -> 99.3 us); the compiler's own choice elsewhere.
 template <int P, bool EXT, bool CULL, bool BINS = false, bool SHFAST = false>
-__global__ __launch_bounds__(256, ((EXT && P == 4) || P == 8) ? 4 : 1) void rc_draw_tiled(RcKernArgs a)
+__global__ __launch_bounds__(256, ((EXT && P == 4) || P == 8) ? 4 : ((EXT && !CULL && P == 2) ? (SHFAST ? 5 : 6) : 1))
+void rc_draw_tiled(RcKernArgs a)
 {
     extern __shared__ __attribute__((aligned(16))) char rc_lds[];
     rc_tiled_body<P, EXT, CULL, BINS, SHFAST>(a, rc_lds);

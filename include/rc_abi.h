@@ -165,14 +165,19 @@ int rc_prepare(int width, int full_height, float fov);
  * arguments, same frames as rc_render, but the device scratch the library needs -- the sine tables
  * and, for RC_VARIANT_CULLED, the per-frame sphere records -- lives in a fixed array inside the
  * library's code object (256 KiB, held by every GPU the library runs on until the process ends), so
- * the call never allocates or frees anything on the device or through an allocating library routine.
+ * the library itself calls no hipMalloc / hipFree and no allocating library routine (what the HIP runtime does
+ * internally to stage a table upload from pageable memory on a format change is the runtime's business).
  * Limits (RC_EINVAL beyond them): width + full_height <= 32768; RC_VARIANT_CULLED: sphere_num <= 8192;
  * device index <= 15.  opts->workspace is ignored.
  * All calls on one GPU share that GPU's array, which keeps the last call's contents; nothing in it has
  * to start at zero (tables and records are rewritten in full before they are read).  When the frame
  * format (width, full_height, fov) differs from the previous call's on that GPU, the new tables are
  * uploaded on opts->stream and the call waits for that stream once (so such a call cannot be captured
- * into a graph: render one frame of the format first).  Calls that overlap on one GPU -- different
+ * into a graph: render one frame of the format first).  A captured call is replayed with the tables' address,
+ * not their contents, so from the first captured call on, the captured frame format stays the only one this
+ * entry point serves on that GPU for the life of the process: a call with another format returns RC_EINVAL
+ * instead of overwriting the tables under the graph (rc_render, whose cache pins captured tables, serves any
+ * number of formats).  Calls that overlap on one GPU -- different
  * streams or threads without ordering between them -- race on the array unless they use the same
  * frame format and none uses RC_VARIANT_CULLED. */
 int rc_render_static(const rc_screen *screen, const rc_scene *scene, const rc_opts *opts);
@@ -338,7 +343,7 @@ const char *rc_version(void);
  * is exported by librc_hip.so with C linkage and the C++ by-value convention of the
  * reference types (Scene embeds vec3, whose copy constructor is user-provided at
  * vec3.h:13-18, so a by-value Scene is passed by invisible reference).  It is declared in
- * rc_dropin.hpp for C++ callers that do not use the reference's own headers; a caller
+ * include/rc_dropin.hpp for C++ callers that do not use the reference's own headers; a caller
  * that does (RayTracingKernel.cpp:3-6) needs no header from this library at all.
  */
 #endif /* RC_ABI_H */

@@ -174,3 +174,27 @@ def test_gather_library_exports_every_declared_symbol():
                             assert (sb, se) == py[k]
                         else:
                             assert sb == se
+
+
+def test_dropin_header_compiles_and_links_a_cpp_caller(tmp_path):
+    """include/rc_dropin.hpp is what a C++ caller WITHOUT the reference's headers includes to call
+    execute_kernel(Screen, Scene) by value (kernel.cu:114-115): it must compile on its own, declare the types
+    with the reference's sizes and non-trivial copy, and link against the library's exported symbol."""
+    src = tmp_path / "caller.cpp"
+    src.write_text(
+        '#include "rc_dropin.hpp"\n'
+        '#include <type_traits>\n'
+        'static_assert(!std::is_trivially_copyable<rc_ref_abi::Scene>::value, "Scene must be passed by invisible reference");\n'
+        'static_assert(std::is_trivially_copyable<rc_ref_abi::Screen>::value, "Screen is a plain aggregate");\n'
+        'int main(int argc, char **) {\n'
+        '    rc_ref_abi::Screen screen = {nullptr, 0, 0, 0};\n'
+        '    rc_ref_abi::Scene scene = {};\n'
+        '    if (argc > 1000) execute_kernel(screen, scene);      // linked, never run here (no GPU)\n'
+        '    return sizeof(scene) == 88 ? 0 : 1;\n'
+        '}\n')
+    exe = tmp_path / "caller"
+    libdir = os.path.dirname(abi.LIB_PATH)
+    subprocess.run(["g++", "-std=c++14", "-Wall", "-Werror", "-I" + os.path.join(ROOT, "include"), str(src), "-o", str(exe),
+                    "-L" + libdir, "-lrc_hip", "-Wl,-rpath," + libdir], check=True)
+    syms = subprocess.run(["nm", "-D", "--undefined-only", str(exe)], capture_output=True, text=True, check=True).stdout
+    assert "execute_kernel" in syms

@@ -1,5 +1,6 @@
 """Guards the documents against rot: every repository path DESIGN.md, INTEGRATION.md, README.md and
-profiles/README.md cite in backticks must exist (reference paths, globs and placeholders are skipped)."""
+profiles/README.md cite in backticks must exist (reference paths, globs and placeholders are skipped), and so
+must every repository file the public headers under include/ name in their comments."""
 import os
 import re
 
@@ -34,3 +35,18 @@ def test_cited_files_exist(doc):
         if not os.path.exists(os.path.join(ROOT, rel)):
             missing.append(p)
     assert not missing, f"{doc} cites files that do not exist: {missing}"
+
+
+@pytest.mark.parametrize("header", sorted(f for f in os.listdir(os.path.join(ROOT, "include")) if f.endswith((".h", ".hpp"))))
+def test_headers_cite_only_files_that_exist(header):
+    """A header's comments may name this repository's files (rc_*.h / rc_*.hpp headers, csrc/..., tests/...,
+    tools/...); each must exist.  Names of the reference's files (Screen.h, kernel.cu ...) are not ours to check."""
+    text = open(os.path.join(ROOT, "include", header)).read()
+    names = set(re.findall(r"\b(?:include/)?(rc_[a-z0-9_]+\.(?:hpp|h))\b", text))
+    names |= set(re.findall(r"\b((?:csrc|tests|tools|cudaraytracing_amd|oracle|examples)/[A-Za-z0-9_./]+\.[a-z]+)\b", text))
+    missing = []
+    for n in sorted(names):
+        cands = [n, "include/" + n, "cudaraytracing_amd/" + n, "cudaraytracing_amd/csrc/" + n, "cudaraytracing_amd/csrc/host/" + n]
+        if not any(os.path.exists(os.path.join(ROOT, c)) for c in cands):
+            missing.append(n)
+    assert not missing, f"include/{header} names files that do not exist: {missing}"

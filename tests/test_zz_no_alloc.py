@@ -107,3 +107,63 @@ def test_static_entry_rejects_sizes_beyond_its_scratch(rclib):
     abi.check(rclib.rc_sync(None))
     arrays.free()
     surf.free()
+
+
+def test_static_entry_under_graph_capture(oracle, rclib):
+    """Runs last in this file (the captured format stays pinned on the GPU for the rest of the process).
+    1. a format that is not loaded cannot be captured; 2. after one plain frame of it, a captured call replays
+    to the oracle's frame; 3. another format is then refused instead of overwriting the tables under the graph,
+    and the replay after the refusal is still the oracle's frame."""
+    w, h, n = 336, 208, 120
+    pos, rad, col = oracle.generate_scene(n, 21)
+    cam = oracle.camera_data((0.2, 0.1, 20), (0.02, 0.04, 0), w, h)
+    want = oracle.render(pos, rad, col, cam, w, h)
+    sc = GpuScene(pos, rad, col)
+    stream = C.c_void_p()
+    abi.check(rclib.rc_stream_create(C.byref(stream)))
+    surf = DeviceBuffer(w * 16 * h)
+    screen = abi.RcScreen(surf.ptr.value, w, h, w * 16)
+    s = sc.scene(cam)
+    opts = abi.RcOpts(stream=stream)
+
+    # 1. make sure another format is the loaded one, then try to capture this one
+    other = abi.RcScreen(surf.ptr.value, 64, 32, 64 * 16)
+    abi.check(rclib.rc_render_static(C.byref(other), C.byref(s), C.byref(opts)), "rc_render_static (other format)")
+    abi.check(rclib.rc_sync(stream))
+    abi.check(rclib.rc_graph_begin(stream))
+    assert rclib.rc_render_static(C.byref(screen), C.byref(s), C.byref(opts)) == abi.RC_EINVAL
+    assert b"not loaded" in rclib.rc_last_error_string()
+    dead = C.c_void_p()
+    rclib.rc_graph_end(stream, C.byref(dead))            # ends the capture (an empty graph, or an error: both fine)
+    rclib.rc_graph_destroy(dead)
+
+    # 2. one plain frame loads the format; the captured call replays to the oracle's frame
+    abi.check(rclib.rc_render_static(C.byref(screen), C.byref(s), C.byref(opts)), "rc_render_static (load)")
+    abi.check(rclib.rc_sync(stream))
+    abi.check(rclib.rc_graph_begin(stream))
+    abi.check(rclib.rc_render_static(C.byref(screen), C.byref(s), C.byref(opts)), "rc_render_static (capture)")
+    graph = C.c_void_p()
+    abi.check(rclib.rc_graph_end(stream, C.byref(graph)), "rc_graph_end")
+    abi.check(rclib.rc_memset(surf.ptr, 0, w * 16 * h, stream))
+    abi.check(rclib.rc_graph_launch(graph, stream))
+    abi.check(rclib.rc_sync(stream))
+    got = np.empty((h, w, 4), np.float32)
+    abi.check(rclib.rc_download_2d(got.ctypes.data_as(C.c_void_p), w * 16, surf.ptr, w * 16, w * 16, h, None))
+    assert_same_bits(got, want, "captured rc_render_static, first replay")
+
+    # 3. another format would overwrite the tables the graph reads: refused, and the replay still matches
+    assert rclib.rc_render_static(C.byref(other), C.byref(s), C.byref(opts)) == abi.RC_EINVAL
+    assert b"captured graph" in rclib.rc_last_error_string()
+    abi.check(rclib.rc_memset(surf.ptr, 0, w * 16 * h, stream))
+    abi.check(rclib.rc_graph_launch(graph, stream))
+    abi.check(rclib.rc_sync(stream))
+    abi.check(rclib.rc_download_2d(got.ctypes.data_as(C.c_void_p), w * 16, surf.ptr, w * 16, w * 16, h, None))
+    assert_same_bits(got, want, "captured rc_render_static, replay after the refused format change")
+    # the captured format itself keeps working, and rc_render serves the other format
+    abi.check(rclib.rc_render_static(C.byref(screen), C.byref(s), C.byref(opts)), "rc_render_static (same format)")
+    abi.check(rclib.rc_render(C.byref(other), C.byref(s), C.byref(opts)), "rc_render (other format)")
+    abi.check(rclib.rc_sync(stream))
+    rclib.rc_graph_destroy(graph)
+    rclib.rc_stream_destroy(stream)
+    surf.free()
+    sc.free()
