@@ -695,7 +695,7 @@ __device__ __forceinline__ bool rc_shadow_blocks(const RcKernArgs &a, const floa
         float m[P];
 #pragma unroll
         for (int p = 0; p < P; p++) m[p] = FAST ? -__builtin_inff() : 0.0f;
-#pragma unroll (P <= 2 ? 2 : 4)   // of 8: deeper unrolling prefetches more records than the register budget holds (spills, measured slower)
+#pragma unroll P <= 2 ? 2 : 4   // of 8: deeper unrolling prefetches more records than the register budget holds (spills, measured slower)
         for (int g = 0; g < kGroupsPerBlock; g++) {
             const float4 H0 = s_rec[(blk * kGroupsPerBlock + g) * 3 + 0];
             const float4 H1 = s_rec[(blk * kGroupsPerBlock + g) * 3 + 1];
