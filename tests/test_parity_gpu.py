@@ -979,6 +979,7 @@ def test_c_gather_one_rank_assembles_pieces(oracle):
     abi.check(lib.rc_memset(full.ptr, 0, w * 16 * h, None))
     g = gather.Gather(1, 0, gather.unique_id())
     parts = 3
+    g.begin(parts, full.ptr, w * 16, h, None)            # one rank: nothing to receive, must be accepted all the same
     for k in range(parts):
         sb, se = gather.sub_band(0, h, parts, k)
         screen = abi.RcScreen(band.ptr.value + sb * w * 16, w, se - sb, w * 16)

@@ -94,7 +94,7 @@ int main()
         double t;
 #define RUN(NAME, KERNEL, GRID, TX)                                                                         \
         t = timed_us([&] { hipLaunchKernelGGL(KERNEL, dim3(GRID), dim3(256), 0, 0, surface, w, h, TX); }, 3000, reps); \
-        printf("%4dx%-4d %-34s %6d wg  %7.2f us  %7.1f GB/s\n", w, h, NAME, GRID, t, mb / t * 1e-3 * 1e6 / 1e3);
+        printf("%4dx%-4d %-34s %6d wg  %7.2f us  %7.1f TB/s\n", w, h, NAME, GRID, t, mb / t * 1e-3 * 1e6 / 1e3);
         RUN("store only, tile P=2", (k_store<2, false>), tiles(2), tx(2));
         RUN("store only, tile P=4", (k_store<4, false>), tiles(4), tx(4));
         RUN("store only, tile P=8", (k_store<8, false>), tiles(8), tx(8));
