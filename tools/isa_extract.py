@@ -50,6 +50,10 @@ def report(sym, title, rank, fname, tests_per_lane, no_mul=False):
         bl = [b for b in bl if not any("v_pk_mul_f32" in i for i in b[1])]
     bl = sorted(bl, key=lambda b: -sum("v_pk_fma_f32" in i for i in b[1]))
     name, ins = bl[rank]
+    for k, i in enumerate(ins):                 # the loop body ends at its first branch; what follows in the
+        if i.split()[0].startswith("s_cbranch"):  # same label-to-label stretch is the fall-through of the rare path
+            ins = ins[:k + 1]
+            break
     hist = collections.Counter(i.split()[0] for i in ins)
     valu = sum(c for op, c in hist.items() if op.startswith("v_"))
     meta = {k: re.search(r"\.%s:\s+(\d+)" % k, text[text.index(".name:           " + sym):][:2000]) for k in ("vgpr_count", "sgpr_count", "private_segment_fixed_size")}
