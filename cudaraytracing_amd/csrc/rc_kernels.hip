@@ -63,10 +63,10 @@ constexpr int kGroup = 4;              // spheres per filter group (48 bytes of 
 // the compiler's general sequences because the operand is first checked to be a normal number well inside the
 // exponent range; anything else (zero, denormals, huge, tiny, infinities, NaN) takes the general sequence.
 //
-// rc_sqrt: the hardware's v_sqrt_f32 is within one ulp, so the correctly rounded root is s, its predecessor or
+// rc_sqrt_core: the hardware's v_sqrt_f32 is within one ulp, so the correctly rounded root is s, its predecessor or
 // its successor; the exact residuals x - (s -+ 1ulp) s (one FMA each, no rounding in the product) decide which --
 // the core of the compiler's own expansion, minus its rescaling of small operands.
-// rc_rcp: one Newton step from v_rcp_f32 (within one ulp), r' = r + r (1 - x r) with the residual exact in an FMA,
+// rc_rcp_core: one Newton step from v_rcp_f32 (within one ulp), r' = r + r (1 - x r) with the residual exact in an FMA,
 // then a second one: the first brings r within half an ulp plus 2^-46 relative, the second rounds correctly.
 // Both are compared against the general sequences for EVERY binary32 mantissa over the whole admitted exponent
 // range on the device itself (rc_selftest_math, tests/test_parity_gpu.py::test_fast_sqrt_rcp_exhaustive).
@@ -90,28 +90,34 @@ __device__ __forceinline__ float rc_rcp_core(float x)
     return r;
 }
 
-__device__ __forceinline__ float rc_sqrt(float x)
-{
-    // wave-uniform choice: one scalar branch, no lane ever takes both paths
-    if (__builtin_amdgcn_ballot_w64(!(x >= 0x1p-96f && x < 0x1p96f)) == 0ull) return rc_sqrt_core(x);
-    asm volatile("" ::: "memory");                           // keeps the general sequence out of the fast path
-    return sqrtf(x);
-}
-
 __device__ __forceinline__ float rc_rcp(float x)
 {
+    // wave-uniform choice: one scalar branch, no lane ever takes both paths
     const float ax = fabsf(x);
     if (__builtin_amdgcn_ballot_w64(!(ax >= 0x1p-96f && ax < 0x1p96f)) == 0ull) return rc_rcp_core(x);
     asm volatile("" ::: "memory");
     return 1.0f / x;
 }
 
+// root = sqrtf(x) and the returned 1.0f / root, both correctly rounded, behind ONE range check: for x in
+// [2^-96, 2^96) the root lies in [2^-48, 2^48], well inside the reciprocal's admitted range.
+__device__ __forceinline__ float rc_sqrt_rcp(float x, float &root)
+{
+    if (__builtin_amdgcn_ballot_w64(!(x >= 0x1p-96f && x < 0x1p96f)) == 0ull) {
+        root = rc_sqrt_core(x);
+        return rc_rcp_core(root);
+    }
+    asm volatile("" ::: "memory");
+    root = sqrtf(x);
+    return 1.0f / root;
+}
+
 // vec3::norm (vec3.h:168-176,89-92) of the un-normalised ray q of kernel.cu:49, in place: ONE reciprocal,
 // three multiplies.  Returns |q| as the reference rounds it.
 __device__ __forceinline__ float rc_normalise(float &x, float &y, float &z)
 {
-    const float len = rc_sqrt((x * x + y * y) + z * z);
-    const float inv = rc_rcp(len);
+    float len;
+    const float inv = rc_sqrt_rcp((x * x + y * y) + z * z, len);
     x = x * inv; y = y * inv; z = z * inv;
     return len;
 }
@@ -271,8 +277,8 @@ __device__ __forceinline__ void rc_ext_ray(const RcKernArgs &a, float minDist, f
 {
     float px = a.ox + dx * minDist, py = a.oy + dy * minDist, pz = a.oz + dz * minDist;
     float lvx = a.lgx - px, lvy = a.lgy - py, lvz = a.lgz - pz;
-    float lightDist = rc_sqrt((lvx * lvx + lvy * lvy) + lvz * lvz);
-    float invL = rc_rcp(lightDist);
+    float lightDist;
+    float invL = rc_sqrt_rcp((lvx * lvx + lvy * lvy) + lvz * lvz, lightDist);
     ex = (px - a.lgx) * invL; ey = (py - a.lgy) * invL; ez = (pz - a.lgz) * invL;
     ldist = lightDist;
 }
@@ -300,7 +306,8 @@ __device__ __forceinline__ void rc_ext_shade(const RcKernArgs &a, int idx, float
     float nx, ny, nz, cr, cg, cb, il;
     if (idx >= 0) {
         nx = px - a.position[3 * idx + 0]; ny = py - a.position[3 * idx + 1]; nz = pz - a.position[3 * idx + 2];
-        float inv = rc_rcp(rc_sqrt((nx * nx + ny * ny) + nz * nz));
+        float nlen;
+        float inv = rc_sqrt_rcp((nx * nx + ny * ny) + nz * nz, nlen);
         nx = nx * inv; ny = ny * inv; nz = nz * inv;
         cr = a.color[3 * idx + 0]; cg = a.color[3 * idx + 1]; cb = a.color[3 * idx + 2];
         il = 0.0f;                                            // evaluated below, only if the pixel is lit
@@ -314,15 +321,16 @@ __device__ __forceinline__ void rc_ext_shade(const RcKernArgs &a, int idx, float
     float c = 0.2f, spec = 0.0f;
     if (!shadowed) {
         float lvx = a.lgx - px, lvy = a.lgy - py, lvz = a.lgz - pz;
-        if (!(ldist >= 0.0f)) ldist = rc_sqrt((lvx * lvx + lvy * lvy) + lvz * lvz);
-        float invL = rc_rcp(ldist);
+        float invL;
+        if (ldist >= 0.0f) invL = rc_rcp(ldist);
+        else invL = rc_sqrt_rcp((lvx * lvx + lvy * lvy) + lvz * lvz, ldist);
         float ldx = lvx * invL, ldy = lvy * invL, ldz = lvz * invL;
         float diff = fmaxf(rc_dot3(nx, ny, nz, ldx, ldy, ldz), 0.0f);
         c = c + diff * 0.5f;
         // Ldir.reflect(N): N * Ldir.dot(N) / N.length() / N.length() * 2 - Ldir  (vec3.h:163-166)
         float dn = rc_dot3(ldx, ldy, ldz, nx, ny, nz);
         float tx = nx * dn, ty = ny * dn, tz = nz * dn;
-        if (idx >= 0) il = rc_rcp(rc_sqrt((nx * nx + ny * ny) + nz * nz));
+        if (idx >= 0) { float nl; il = rc_sqrt_rcp((nx * nx + ny * ny) + nz * nz, nl); }
         tx = tx * il; ty = ty * il; tz = tz * il;
         tx = tx * il; ty = ty * il; tz = tz * il;
         tx = tx * 2.0f; ty = ty * 2.0f; tz = tz * 2.0f;
