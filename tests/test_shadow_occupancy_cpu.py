@@ -1,8 +1,8 @@
 """Why the EXT shadow pass does not repack its rays: with waves that hold no hit pixel skipping the pass (they do),
 the pixel slots a wave-level or workgroup-level compaction could still remove are a few per cent, because hit pixels
 are spatially coherent (the plane fills whole tiles, empty sky fills others).  Counted on the oracle's own EXT frame
-of the 1920x1080 x 64 workload for both wave-tile shapes the EXT kernels use; the 3840x2160 x 1024 frame gives
-84 280 slots today against 83 690 compacted per wave (0.7 %), recorded in DESIGN.md."""
+of the 1920x1080 x 64 workload for both wave-tile shapes the EXT kernels use (the 3840x2160 x 1024 frame, too slow
+for this suite, gives 84 280 slots today against 83 690 compacted per wave: 0.7 %)."""
 import numpy as np
 
 from cudaraytracing_amd import configs

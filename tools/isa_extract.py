@@ -1,5 +1,5 @@
 """Inner loops of the draw kernels as the compiler emits them for gfx950, with an instruction histogram: the
-evidence behind the per-test instruction counts quoted in DESIGN.md.
+evidence behind the per-test instruction counts the kernels' comments and the bench line quote.
 
     python tools/isa_extract.py [out_dir]        (default: profiles/, files r3_isa_*.txt)
 

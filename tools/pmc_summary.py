@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """Summarises a tools/profile.sh output directory.
 
-    python tools/pmc_summary.py gpurun_out/prof_<tag> [--update profiles/counters.json] [--round r2]
+    python tools/pmc_summary.py gpurun_out/prof_<tag> [--update profiles/counters.json] [--round r3]
 
 Prints, for the draw kernel of that run: the rocprofv3 --stats table, the average duration of the
 TIMED launches only (the bench line in trace.log says how many warm-up and clock-ramp launches
@@ -42,7 +42,7 @@ def main():
     args = sys.argv[1:]
     d = args[0]
     update = args[args.index("--update") + 1] if "--update" in args else None
-    rnd = args[args.index("--round") + 1] if "--round" in args else "r2"
+    rnd = args[args.index("--round") + 1] if "--round" in args else "r3"
     workload = open(os.path.join(d, "workload.txt")).read().strip() if os.path.exists(os.path.join(d, "workload.txt")) else None
     print(f"# workload: {workload}   directory: {d}")
 
