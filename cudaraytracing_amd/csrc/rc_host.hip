@@ -279,6 +279,18 @@ int rc_enqueue_frame(const rc_screen *screen, const rc_scene *scene, const rc_op
         a.pu_il = 1.0f / sqrtf((a.pux * a.pux + a.puy * a.puy) + a.puz * a.puz);
         a.plane_num = a.plane_h - ((a.pnx * a.ox + a.pny * a.oy) + a.pnz * a.oz);
         a.plane_num_light = a.plane_h - ((a.pnx * a.lgx + a.pny * a.lgy) + a.pnz * a.lgz);
+        // which pixels can hit the plane at all (see the tiled kernel): only for a normal with ONE non-zero, finite
+        // component and a finite, non-zero numerator
+        const float pn[3] = {a.pnx, a.pny, a.pnz};
+        int nonzero = 0, axis = 0;
+        for (int k = 0; k < 3; k++)
+            if (!(pn[k] == 0.0f)) { nonzero++; axis = k; }           // NaN counts as non-zero
+        a.plane_axis = 0;
+        a.plane_side = 0.0f;
+        if (a.has_plane && nonzero == 1 && std::isfinite(pn[axis]) && std::isfinite(a.plane_num) && a.plane_num != 0.0f) {
+            a.plane_axis = axis;
+            a.plane_side = ((a.plane_num > 0.0f) == (pn[axis] > 0.0f)) ? 1.0f : -1.0f;
+        }
     }
 
     {

@@ -55,6 +55,10 @@ struct RcKernArgs {
     float pu_il;             // 1 / sqrt(pu.pu), the reciprocal length vec3::reflect divides by twice
     float plane_num;         // plane_h - pn.o      numerator of the primary plane test
     float plane_num_light;   // plane_h - pn.light  numerator of the plane's shadow test
+    int plane_axis;          // the plane normal's single non-zero component (0 if plane_side is 0)
+    float plane_side;        // sign a ray's un-normalised component along plane_axis must have to hit the plane: +1 / -1;
+                             // 0 = unknown, every pixel takes the plane test (normal with several non-zero components,
+                             // plane through the camera, non-finite data)
     // culled variant: sphere records built once per frame by rc_launch_records (else NULL)
     const float4 *records;   // [n] {alpha, gamma, beta, always ? 1 : 0}
     const unsigned char *bins; // culled variant, level 0: per-bin sphere lists (else NULL); bins_bytes available

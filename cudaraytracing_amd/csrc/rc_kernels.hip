@@ -913,11 +913,15 @@ __device__ __forceinline__ void rc_shadow_pass(const RcKernArgs &a, char *lds,
     float fu[P], fv[P], flen[P];
 #pragma unroll
     for (int p = 0; p < P; p++) { fu[p] = 0.0f; fv[p] = 0.0f; flen[p] = __builtin_inff(); }
+    // One barrier serves three purposes: every wave has finished with the primary records (the light records
+    // overwrite them); the waves' votes on a common dominant axis are exchanged; and so is "this wave casts a
+    // shadow ray at all" -- a workgroup over background only (no wave with a hit pixel) leaves here, all waves
+    // together, without building light records it would never read.
+    __shared__ unsigned s_vote[8];
+    unsigned ok = 0u;
     if (!CULL && SHFAST) {
-        __shared__ unsigned s_axis[4];
         // bit k of `ok`: candidate k = (axis k >> 1, sign k & 1 ? -1 : +1) has s e_m >= 1/2 for every shadow
         // ray of this wave (a wave without shadow rays accepts every candidate)
-        unsigned ok = 0u;
 #pragma unroll
         for (int k = 0; k < 6; k++) {
             bool bad = false;
@@ -928,9 +932,15 @@ __device__ __forceinline__ void rc_shadow_pass(const RcKernArgs &a, char *lds,
             }
             if (__builtin_amdgcn_ballot_w64(bad) == 0ull) ok |= 1u << k;
         }
-        if ((tid & 63) == 0) s_axis[tid >> 6] = ok;
-        __syncthreads();
-        ok = s_axis[0] & s_axis[1] & s_axis[2] & s_axis[3];
+    }
+    if ((tid & 63) == 0) {
+        s_vote[tid >> 6] = ok;
+        s_vote[4 + (tid >> 6)] = wave_has_hits ? 1u : 0u;
+    }
+    __syncthreads();
+    if ((s_vote[4] | s_vote[5] | s_vote[6] | s_vote[7]) == 0u) return;
+    if (!CULL && SHFAST) {
+        ok = s_vote[0] & s_vote[1] & s_vote[2] & s_vote[3];
         if (ok != 0u) {
             const int bk = __builtin_ctz(ok);
             fast_axis = bk >> 1;
@@ -973,7 +983,7 @@ __device__ __forceinline__ void rc_shadow_pass(const RcKernArgs &a, char *lds,
     for (int base = 0; base < a.n; base += cap) {
         const int cn = min(a.n - base, cap);
         const int cnb = (cn + kBlockSpheres - 1) & ~(kBlockSpheres - 1);
-        __syncthreads();                           // primary records / previous chunk consumed
+        if (base > 0) __syncthreads();             // previous chunk consumed (the primary records: barrier above)
         {
             float *rec = reinterpret_cast<float *>(s_rec);
             unsigned char *flagb = reinterpret_cast<unsigned char *>(s_flag);
@@ -1083,13 +1093,21 @@ __device__ __forceinline__ void rc_tiled_body(const RcKernArgs &a, char *lds)
     // out (2-8 tiles per workgroup measured 5-25 % slower at 3840x2160 x 1024 spheres even
     // though the sphere records would be built less often).
     {
-        // LAZY (brute-force REF kernels): the normalised direction d -- an IEEE square root, an IEEE
+        // LAZY (brute-force kernels): the normalised direction d -- an IEEE square root, an IEEE
         // division and three products per pixel -- and the wave tile's interval bounds are needed by the
-        // exact re-tests and the shading only, so they are evaluated when the wave first meets a flagged
-        // block; a wave over empty background never pays for them.  Until then (dx, dy, dz) hold the
-        // un-normalised q of kernel.cu:49.  EXT needs d for every pixel (plane test), the culled variant
-        // its bounds at once.
-        constexpr bool LAZY = !EXT && !CULL;
+        // exact re-tests, the plane test and the shading only, so they are evaluated when the wave first
+        // meets a flagged block (or, in EXT mode, after the loop if some pixel of the wave can hit the plane);
+        // a wave over empty background never pays for them.  Until then (dx, dy, dz) hold the un-normalised
+        // q of kernel.cu:49.  The culled variant needs its bounds at once.
+        //
+        // EXT: can this pixel hit the plane at all?  The plane test accepts t = plane_num / (n.d) - 1e-6 > 0
+        // only, so n.d must be non-zero with the sign of plane_num.  When the plane's normal has a single
+        // non-zero component n_a (the host checks; plane_side = sign(plane_num) sign(n_a), else 0), the other
+        // two products are zeros of either sign and n.d has the sign of n_a d_a = the sign of n_a q_a (d = q
+        // times a positive number; if the product underflows to zero, n.d is zero and the test rejects): a
+        // pixel with sign(q_a) != plane_side cannot hit.  plane_side = 0 switches the shortcut off (every pixel
+        // "can"); NaN components compare false either way and are rejected by the plane test itself.
+        constexpr bool LAZY = !CULL;
         RC_COUNT(8, 1);
         const int tyi = blockIdx.y, txi = blockIdx.x;
         const int x0 = txi * (2 * TW) + (wave & 1) * TW + lx;
@@ -1110,6 +1128,7 @@ __device__ __forceinline__ void rc_tiled_body(const RcKernArgs &a, char *lds)
         float fa[P], len[P], dx[P], dy[P], dz[P], minDist[P];
         int idx[P];
         bool lane_forced = (a.cam_ok == 0);
+        bool plane_maybe = false;                   // EXT: some pixel of this lane can hit the plane
         const float fb = sy;
 #pragma unroll
         for (int p = 0; p < P; p++) {
@@ -1121,6 +1140,10 @@ __device__ __forceinline__ void rc_tiled_body(const RcKernArgs &a, char *lds)
             const float wx = a.ux * sy, wy = a.uy * sy, wz = a.uz * sy;
             qx = qx + wx; qy = qy + wy; qz = qz + wz;
             dx[p] = qx; dy[p] = qy; dz[p] = qz;
+            if (EXT && a.has_plane) {
+                const float qa = a.plane_axis == 0 ? qx : (a.plane_axis == 1 ? qy : qz);
+                plane_maybe = plane_maybe || (a.plane_side == 0.0f) || (a.plane_side > 0.0f ? (qa > 0.0f) : (qa < 0.0f));
+            }
             if (LAZY) {
                 // The filter's threshold: a LOWER bound of the reference's |q| (a lower threshold can only
                 // flag more).  The hardware square root is within one ulp, so times (1 - 2^-21) it is
@@ -1373,8 +1396,16 @@ __device__ __forceinline__ void rc_tiled_body(const RcKernArgs &a, char *lds)
 #pragma unroll
         for (int p = 0; p < P; p++) ldist[p] = -1.0f;
         if (EXT) {
+            if (LAZY && !have_d && __builtin_amdgcn_ballot_w64(plane_maybe) != 0ull) {
 #pragma unroll
-            for (int p = 0; p < P; p++) rc_plane_test(a, dx[p], dy[p], dz[p], minDist[p], idx[p]);
+                for (int p = 0; p < P; p++) rc_normalise(dx[p], dy[p], dz[p]);
+                have_d = true;
+            }
+            // without d by now: no pixel of this wave hit a sphere and none can hit the plane
+            if (have_d) {
+#pragma unroll
+                for (int p = 0; p < P; p++) rc_plane_test(a, dx[p], dy[p], dz[p], minDist[p], idx[p]);
+            }
             if (a.shadows) {
                 float ex[P], ey[P], ez[P];
 #pragma unroll

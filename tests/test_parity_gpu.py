@@ -327,6 +327,34 @@ def test_ext_ragged_and_multichunk(oracle):
             assert_same_bits(got, want, f"EXT {w}x{h} n={n} variant {variant} tuning {tuning}")
 
 
+def test_ext_axis_aligned_planes_and_background_waves(oracle):
+    """Planes whose normal has ONE non-zero component let the kernels decide per pixel, from the sign of the
+    un-normalised ray's component along that axis, that the plane cannot be hit, and skip the ray normalisation and
+    the plane test for waves (and the light records for workgroups) that see background only.  Every axis, both
+    signs of the normal, zeros of either sign in the other components, planes in front of / behind / through the
+    camera, cameras looking every way incl. straight along the plane, with few spheres (large background) and
+    with none: bit-identical to the oracle on all EXT variants."""
+    rng = np.random.default_rng(77)
+    w, h = 208, 120
+    normals = [(0.0, 1.0, 0.0), (0.0, -2.5, -0.0), (1.0, 0.0, 0.0), (-0.5, -0.0, 0.0), (0.0, 0.0, 3.0), (-0.0, 0.0, -1.0),
+               (0.0, 1.0, 1e-30), (0.0, 0.0, 0.0)]
+    it = 0
+    for normal in normals:
+        for plane_h in (-6.0, 4.0, 0.0):
+            for n in (0, 5):
+                pos, rad, col = oracle.generate_scene(max(n, 1), 30 + it)
+                pos, rad, col = pos[:n], rad[:n], col[:n]
+                cpos = (float(rng.uniform(-3, 3)), float(rng.uniform(-3, 3)), 20.0) if it % 3 else (0.0, 0.0, 20.0)
+                rot = [(0.0, 0.0, 0.0), (0.4, -0.3, 0.0), (-1.2, 2.0, 0.0), (1.5707964, 0.0, 0.0), (0.0, 1.5707964, 0.0)][it % 5]
+                cam = oracle.camera_data(cpos, rot, w, h)
+                ext = _default_ext(oracle, plane_normal=normal, plane_h=plane_h, light_pos=(3.0, 9.0, 14.0))
+                want = oracle.render(pos, rad, col, cam, w, h, ext=ext)
+                for variant in EXT_VARIANTS:
+                    got = pixels(gpu_render(pos, rad, col, cam, w, h, variant=variant, ext=ext), w)
+                    assert_same_bits(got, want, f"axis plane {normal} h={plane_h} n={n} cam={cpos} rot={rot} variant={variant}")
+                it += 1
+
+
 def test_ext_soak_tiled_vs_literal_on_device(oracle):
     """EXT mode, filter soundness incl. the shadow-ray filter: random scenes, lights and planes with
     the camera and the light near sphere surfaces; tiled / culled kernels against the literal EXT
