@@ -377,7 +377,11 @@ def test_ext_soak_tiled_vs_literal_on_device(oracle):
         f = -dirv
         rot = (float(np.arcsin(np.clip(f[1], -1, 1))) + float(rng.normal() * 0.2), float(np.arctan2(-f[0], -f[2])) + float(rng.normal() * 0.2), 0.0)
         cam = oracle.camera_data(cpos, rot, w, h)
-        ext = _default_ext(oracle, light_pos=lpos, plane_normal=tuple(float(v) for v in rng.normal(size=3)),
+        normal = rng.normal(size=3)
+        if it % 3 == 2:                              # axis-aligned planes: the kernels' "can this pixel reach the plane" shortcut
+            keep = int(rng.integers(3))
+            normal = np.array([normal[k] if k == keep else 0.0 * rng.choice([-1.0, 1.0]) for k in range(3)])
+        ext = _default_ext(oracle, light_pos=lpos, plane_normal=tuple(float(v) for v in normal),
                            plane_h=float(rng.uniform(-spread, spread)), has_plane=int(rng.integers(2)))
         scene = GpuScene(pos, rad, col)
         want = pixels(gpu_render(pos, rad, col, cam, w, h, variant=abi.VARIANT_LITERAL, scene=scene, ext=ext), w)
