@@ -897,6 +897,13 @@ def main():
             out["bands_check"] = res
     emit()
 
+    if world > 1:
+        # The line is out; a rank stuck in communicator teardown (a peer that died in the leg above) must not keep
+        # the launcher waiting.
+        import threading
+        late = threading.Timer(60.0, lambda: os._exit(0))
+        late.daemon = True
+        late.start()
     if cgather is not None:
         cgather.destroy()
     if use_dist:
