@@ -173,13 +173,13 @@ def test_filter_soak_tiled_vs_literal_on_device(oracle):
         dirv = rng.normal(size=3); dirv /= np.linalg.norm(dirv)
         off = 1.0 + rng.choice([-1.0, 1.0]) * 10.0 ** rng.uniform(-7, 1)
         cpos = tuple(float(v) for v in (pos[k] + dirv * rad[k] * off))
-        if it % 2 == 0:      # look at the sphere
+        if it % 3 != 2:      # look at the sphere (periods 3 and 5 here against the variants' 4: every combination comes up)
             f = -dirv
             rot = (float(np.arcsin(np.clip(f[1], -1, 1))), float(np.arctan2(-f[0], -f[2])), 0.0)
         else:
             rot = (float(rng.uniform(-3.2, 3.2)), float(rng.uniform(-3.2, 3.2)), 0.0)
         cam = oracle.camera_data(cpos, rot, w, h)
-        if it % 4 == 3:
+        if it % 5 == 4:
             # cameras the reference's Camera class cannot produce but its CameraData struct can carry:
             # other fields of view and aspects, basis vectors that are neither unit nor orthogonal
             from gpu_util import to_rc_camera
@@ -377,8 +377,17 @@ def test_ext_soak_tiled_vs_literal_on_device(oracle):
         f = -dirv
         rot = (float(np.arcsin(np.clip(f[1], -1, 1))) + float(rng.normal() * 0.2), float(np.arctan2(-f[0], -f[2])) + float(rng.normal() * 0.2), 0.0)
         cam = oracle.camera_data(cpos, rot, w, h)
+        if it % 5 == 4:                              # basis vectors neither unit nor orthogonal, other fields of view
+            from gpu_util import to_rc_camera
+            cam = to_rc_camera(cam)
+            cam.fov = float(10.0 ** rng.uniform(-2, 0.49))
+            cam.aspect = float(10.0 ** rng.uniform(-0.7, 0.7))
+            for v in (cam.forward, cam.up, cam.right):
+                sc_, sh_ = float(10.0 ** rng.uniform(-0.3, 0.3)), rng.normal(size=3) * 0.05
+                v.x, v.y, v.z = v.x * sc_ + float(sh_[0]), v.y * sc_ + float(sh_[1]), v.z * sc_ + float(sh_[2])
         normal = rng.normal(size=3)
-        if it % 3 == 2:                              # axis-aligned planes: the kernels' "can this pixel reach the plane" shortcut
+        if it % 4 == 3:                              # axis-aligned planes: the kernels' "can this pixel reach the plane" shortcut
+            # (period 4 against the variants' period 3 and the filter forms' period 6: every combination comes up)
             keep = int(rng.integers(3))
             normal = np.array([normal[k] if k == keep else 0.0 * rng.choice([-1.0, 1.0]) for k in range(3)])
         ext = _default_ext(oracle, light_pos=lpos, plane_normal=tuple(float(v) for v in normal),
