@@ -358,12 +358,12 @@ def test_ext_axis_aligned_planes_and_background_waves(oracle):
 def test_ext_soak_tiled_vs_literal_on_device(oracle):
     """EXT mode, filter soundness incl. the shadow-ray filter: random scenes, lights and planes with
     the camera and the light near sphere surfaces; tiled / culled kernels against the literal EXT
-    kernel on the device (RC_EXT_SOAK_SCENES scenes, RC_SOAK_SEED)."""
+    kernel on the device (RC_EXT_SOAK_SCENES scenes of up to RC_EXT_SOAK_NMAX spheres, RC_SOAK_SEED)."""
     rng = np.random.default_rng(int(os.environ.get("RC_SOAK_SEED", "99")) + 1)
     w, h = 160, 88
     variants = [abi.VARIANT_TILED2, abi.VARIANT_TILED4, abi.VARIANT_CULLED]
     for it in range(int(os.environ.get("RC_EXT_SOAK_SCENES", "150"))):
-        n = int(rng.integers(1, 90))
+        n = int(rng.integers(1, int(os.environ.get("RC_EXT_SOAK_NMAX", "90"))))    # > 1024: several LDS passes, any-hit exit
         spread = 10.0 ** rng.uniform(-0.5, 1.5)
         pos = rng.uniform(-spread, spread, (n, 3)).astype(np.float32)
         rad = (spread * 10.0 ** rng.uniform(-2.5, -0.3, n)).astype(np.float32)
