@@ -1673,20 +1673,23 @@ hipError_t rc_launch_draw(const RcKernArgs &a, int variant, int compute_units, h
     if (variant == RC_KVARIANT_TILED2) return rc_launch_tiled<2>(a, stream);
     if (variant == RC_KVARIANT_TILED4) return rc_launch_tiled<4>(a, stream);
     if (variant == RC_KVARIANT_TILED8) return a.ext_mode ? rc_launch_tiled<4>(a, stream) : rc_launch_tiled<8>(a, stream);
-    // Automatic: more pixels per lane share more of the per-sphere work, but the frame must
-    // still cut into enough workgroups to fill the chip: >= 5 per CU for 4 pixels per lane, >= 9 per CU for 8
-    // (tools/p_sweep.py, 8 formats x 5 sphere counts: 1280x768 -> 2, 1920x1080 -> 4, 3840x2160 and up -> 8;
-    // with 7-8 workgroups per CU -- 2560x1440, 3840x1080, a 7680x540 band -- 8 pixels per lane win by at most
-    // 1.5 % at 1024 spheres and more, and lose 3-20 % below that and 8-16 % on the band).
+    // Automatic: more pixels per lane share more of the per-sphere work, but the frame must still cut into enough
+    // workgroups to fill the chip (tools/p_sweep.py: 6 frame formats and 2 row bands of a 7680x4320 frame x 5 sphere
+    // counts, each with every choice forced).  REF: 4 pixels per lane from 5 workgroups per CU; 8 from 9 per CU
+    // (3840x2160 and up) -- and, from 1024 spheres, already from 7 per CU: 2560x1440, 3840x1080 and a 7680x540
+    // band then gain 1-7 % from 8 pixels per lane and lose 3-5 % with fewer spheres.  (With 4 workgroups per CU,
+    // one round, 8 pixels per lane lose 11-16 % at 1920x1080 but win 4 % on a 7680x270 band: no rule on counts
+    // alone gets both, and they stay at 4.)
     const long long want = 5LL * compute_units;
-    const long long want8 = 9LL * compute_units;
+    const long long want8 = (a.n >= 1024 ? 7LL : 9LL) * compute_units;
     // EXT keeps shadow-ray state per pixel: at most 4 pixels per lane.  The culled variant
     // prefers small wave tiles (fewer pixels share a visited sphere): 4 at most as well.
     if (!a.ext_mode && !a.cull && rc_tile_count<8>(a) >= want8) return rc_launch_tiled<8>(a, stream);
-    // EXT below 2048 spheres: 4 pixels per lane pay only from 10 workgroups per CU (tools/p_sweep.py, 1920x1080:
-    // 2 pixels per lane 2 % faster at 64 spheres, 6 % at 256, 5 % at 1024, but 5 % slower at 4096; at
-    // 2560x1440 4 pixels per lane win at every count).
-    const long long want4 = (a.ext_mode && !a.cull && a.n < 2048) ? 2 * want : want;
+    // EXT: the 2-pixel kernels run at 5-6 waves per SIMD, the 4-pixel ones at 4, so 4 pixels per lane need more
+    // workgroups to pay: from 2048 spheres 5 per CU as above; below that 10 per CU (1920x1080 stays at 2: equal at
+    // 1024 spheres, 2 pixels per lane 8 % faster at 64); up to 256 spheres 24 per CU (2560x1440, 3840x1080 and the
+    // 7680x540 band are 5-9 % faster with 2; 3840x2160 keeps 4: 4 % faster at 256 spheres, 3 % slower at 64).
+    const long long want4 = (a.ext_mode && !a.cull && a.n < 2048) ? (a.n <= 256 ? 24LL * compute_units : 2 * want) : want;
     if (rc_tile_count<4>(a) >= want4) return rc_launch_tiled<4>(a, stream);
     return rc_launch_tiled<2>(a, stream);
 }

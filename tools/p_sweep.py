@@ -8,7 +8,10 @@ from cudaraytracing_amd import abi, configs
 from cudaraytracing_amd.host import Camera, DeviceBuffer, generate_scene
 
 shading = sys.argv[1] if len(sys.argv) > 1 else "ref"
-formats = [(640, 480), (1280, 768), (1920, 1080), (2560, 1440), (3840, 1080), (3840, 2160), (7680, 270), (7680, 540)]
+# (width, rows rendered, height of the whole frame, first row): the last two are row bands of a 7680x4320 frame (one of 16
+# and one of 8, from the middle, where the spheres are), rendered as bands -- the camera sees the whole frame
+formats = [(640, 480, 480, 0), (1280, 768, 768, 0), (1920, 1080, 1080, 0), (2560, 1440, 1440, 0), (3840, 1080, 1080, 0),
+           (3840, 2160, 2160, 0), (7680, 270, 4320, 2160), (7680, 540, 4320, 2160)]
 counts = [16, 64, 256, 1024, 4096]
 variants = [("P2", abi.VARIANT_TILED2, 2), ("P4", abi.VARIANT_TILED4, 4)] + ([("P8", abi.VARIANT_TILED8, 8)] if shading == "ref" else [])
 lib = abi.load()
@@ -24,12 +27,12 @@ for n in counts:
         b = DeviceBuffer(max(a.nbytes, 4)); b.upload(a); bufs.append(b)
     scene = abi.RcScene(); scene.sphere_num = n
     scene.position, scene.radius, scene.color = (b.ptr.value for b in bufs)
-    for (w, h) in formats:
-        cam = Camera(w, h); cam.position = (0.0, 0.0, 20.0); scene.cam = cam.get_data()
+    for (w, h, full_h, y0) in formats:
+        cam = Camera(w, full_h); cam.position = (0.0, 0.0, 20.0); scene.cam = cam.get_data()
         screen = abi.RcScreen(surf.ptr.value, w, h, w * 16)
         row = []
         for name, v, p in variants:
-            opts = abi.RcOpts(variant=v)
+            opts = abi.RcOpts(variant=v, y_offset=y0, full_height=full_h)
             if shading == "ext":
                 opts.mode = abi.MODE_EXT; opts.ext = C.pointer(ext)
             est = max(1, int(0.06 / (1e-12 * w * h * max(n, 8) / 25)))
@@ -42,7 +45,7 @@ for n in counts:
             ms = C.c_float(); lib.rc_event_elapsed_ms(e0, e1, C.byref(ms))
             tiles = ((w + 16 * p - 1) // (16 * p)) * ((h + 15) // 16)
             row.append((name, tiles, ms.value / reps))
-        opts = abi.RcOpts(variant=abi.VARIANT_AUTO)
+        opts = abi.RcOpts(variant=abi.VARIANT_AUTO, y_offset=y0, full_height=full_h)
         if shading == "ext":
             opts.mode = abi.MODE_EXT; opts.ext = C.pointer(ext)
         for _ in range(reps): lib.rc_render(C.byref(screen), C.byref(scene), C.byref(opts))
@@ -53,6 +56,7 @@ for n in counts:
         ms = C.c_float(); lib.rc_event_elapsed_ms(e0, e1, C.byref(ms))
         best = min(row, key=lambda r: r[2])
         cells = "  ".join(f"{nm} {t:6d} wg {m:8.4f} ms{'*' if nm == best[0] else ' '}" for nm, t, m in row)
-        print(f"n={n:5d} {w:5d}x{h:<5d} {cells}  auto {ms.value / reps:8.4f} ms ({ms.value / reps / best[2]:.3f} x best)", flush=True)
+        shape = f"{w}x{h}" + (f" of {full_h}" if full_h != h else "")
+        print(f"n={n:5d} {shape:>17s} {cells}  auto {ms.value / reps:8.4f} ms ({ms.value / reps / best[2]:.3f} x best)", flush=True)
     for b in bufs:
         b.free()
