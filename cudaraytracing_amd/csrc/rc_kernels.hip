@@ -1686,10 +1686,11 @@ hipError_t rc_launch_draw(const RcKernArgs &a, int variant, int compute_units, h
     // prefers small wave tiles (fewer pixels share a visited sphere): 4 at most as well.
     if (!a.ext_mode && !a.cull && rc_tile_count<8>(a) >= want8) return rc_launch_tiled<8>(a, stream);
     // EXT: the 2-pixel kernels run at 5-6 waves per SIMD, the 4-pixel ones at 4, so 4 pixels per lane need more
-    // workgroups to pay: from 2048 spheres 5 per CU as above; below that 10 per CU (1920x1080 stays at 2: equal at
-    // 1024 spheres, 2 pixels per lane 8 % faster at 64); up to 256 spheres 24 per CU (2560x1440, 3840x1080 and the
-    // 7680x540 band are 5-9 % faster with 2; 3840x2160 keeps 4: 4 % faster at 256 spheres, 3 % slower at 64).
-    const long long want4 = (a.ext_mode && !a.cull && a.n < 2048) ? (a.n <= 256 ? 24LL * compute_units : 2 * want) : want;
+    // workgroups to pay: above 2048 spheres (several LDS passes) 5 per CU as above; up to 2048 spheres 10 per CU
+    // (1920x1080 stays at 2: equal at 1024 spheres, 3 % faster at 2048); below 1024 spheres 24 per CU (2560x1440,
+    // 3840x1080 and the 7680x540 band are 3-9 % faster with 2; 3840x2160 keeps 4: 4-7 % faster from 256 spheres,
+    // 3 % slower at 64).
+    const long long want4 = (a.ext_mode && !a.cull && a.n <= 2048) ? (a.n < 1024 ? 24LL * compute_units : 2 * want) : want;
     if (rc_tile_count<4>(a) >= want4) return rc_launch_tiled<4>(a, stream);
     return rc_launch_tiled<2>(a, stream);
 }

@@ -1,7 +1,7 @@
 """Pixels-per-lane crossover of the brute-force REF kernels: every frame format x sphere count below with 2, 4 and
 8 pixels per lane forced (rc_opts.variant), in one process so that all numbers share one clock state.  Prints the
 workgroup count of each choice and marks the fastest: the data behind the automatic choice in rc_launch_draw.
-    python tools/p_sweep.py [ref|ext]"""
+    python tools/p_sweep.py [ref|ext] [count,count,...]"""
 import ctypes as C, os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from cudaraytracing_amd import abi, configs
@@ -12,7 +12,7 @@ shading = sys.argv[1] if len(sys.argv) > 1 else "ref"
 # and one of 8, from the middle, where the spheres are), rendered as bands -- the camera sees the whole frame
 formats = [(640, 480, 480, 0), (1280, 768, 768, 0), (1920, 1080, 1080, 0), (2560, 1440, 1440, 0), (3840, 1080, 1080, 0),
            (3840, 2160, 2160, 0), (7680, 270, 4320, 2160), (7680, 540, 4320, 2160)]
-counts = [16, 64, 256, 1024, 4096]
+counts = [int(c) for c in sys.argv[2].split(",")] if len(sys.argv) > 2 else [16, 64, 256, 1024, 4096]
 variants = [("P2", abi.VARIANT_TILED2, 2), ("P4", abi.VARIANT_TILED4, 4)] + ([("P8", abi.VARIANT_TILED8, 8)] if shading == "ref" else [])
 lib = abi.load()
 e0, e1 = C.c_void_p(), C.c_void_p()
