@@ -67,5 +67,5 @@ def pixels_per_lane(width, rows, n, ext, culled, compute_units):
     want = 5 * compute_units
     if not ext and not culled and tiles(8) >= (7 if n >= 1024 else 9) * compute_units:
         return 8
-    want4 = ((24 * compute_units if n < 1024 else 2 * want) if (ext and not culled and n <= 2048) else want)
+    want4 = ((24 * compute_units if n < 768 else 2 * want) if (ext and not culled and n <= 2048) else want)
     return 4 if tiles(4) >= want4 else 2

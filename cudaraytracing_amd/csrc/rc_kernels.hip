@@ -1626,6 +1626,11 @@ static hipError_t rc_launch_tiled(RcKernArgs a, hipStream_t stream)
                              (a.n >= RC_SHADOW_FAST_MIN && !(a.tuning & RC_KTUNE_SHADOW_AXIS_OFF));
     a.shadow_fast = (a.ext_mode && a.shadows && !a.cull && axis_wanted) ? 1 : 0;
     a.lds_exact = (!a.cull && a.lds_cap <= RC_LDS_EXACT_MAX && !(a.tuning & RC_KTUNE_NO_LDS_EXACT)) ? 1 : 0;
+    // The 2-pixel EXT kernels are built for 6 (dominant-axis form: 5) workgroups per CU; the staged exact-test terms
+    // must not be what limits them to fewer (160 KB of LDS per CU: at 1024 spheres 33 KB each, four workgroups).
+    // 1920x1080 x 1024 EXT 0.274 vs 0.280 ms, a 7680x270 band 0.260 vs 0.272 ms; at 768 spheres staging still fits.
+    if (P == 2 && a.ext_mode && !a.cull && a.lds_exact &&
+        rc_lds_bytes_exact(a.lds_cap) * (a.shadow_fast ? 5 : 6) > 160u * 1024u) a.lds_exact = 0;
     a.near_skip = (a.tuning & RC_KTUNE_NO_NEAR_SKIP) ? 0 : 1;
     const size_t lds_plain = a.lds_exact ? rc_lds_bytes_exact(a.lds_cap) : rc_lds_bytes(a.lds_cap);
     const dim3 grid((unsigned)a.tiles_x, (unsigned)a.tiles_y);
@@ -1687,10 +1692,10 @@ hipError_t rc_launch_draw(const RcKernArgs &a, int variant, int compute_units, h
     if (!a.ext_mode && !a.cull && rc_tile_count<8>(a) >= want8) return rc_launch_tiled<8>(a, stream);
     // EXT: the 2-pixel kernels run at 5-6 waves per SIMD, the 4-pixel ones at 4, so 4 pixels per lane need more
     // workgroups to pay: above 2048 spheres (several LDS passes) 5 per CU as above; up to 2048 spheres 10 per CU
-    // (1920x1080 stays at 2: equal at 1024 spheres, 3 % faster at 2048); below 1024 spheres 24 per CU (2560x1440,
-    // 3840x1080 and the 7680x540 band are 3-9 % faster with 2; 3840x2160 keeps 4: 4-7 % faster from 256 spheres,
-    // 3 % slower at 64).
-    const long long want4 = (a.ext_mode && !a.cull && a.n <= 2048) ? (a.n < 1024 ? 24LL * compute_units : 2 * want) : want;
+    // (1920x1080 stays at 2: equal at 1024 spheres, 3 % faster at 2048); below 768 spheres 24 per CU (2560x1440,
+    // 3840x1080 and the 7680x540 band are 2-9 % faster with 2 up to 512 spheres, even at 768, 4 % slower at 900;
+    // 3840x2160 keeps 4: 4-7 % faster from 256 spheres, 3 % slower at 64).
+    const long long want4 = (a.ext_mode && !a.cull && a.n <= 2048) ? (a.n < 768 ? 24LL * compute_units : 2 * want) : want;
     if (rc_tile_count<4>(a) >= want4) return rc_launch_tiled<4>(a, stream);
     return rc_launch_tiled<2>(a, stream);
 }

@@ -1,13 +1,14 @@
 """Pixels-per-lane crossover of the brute-force REF kernels: every frame format x sphere count below with 2, 4 and
 8 pixels per lane forced (rc_opts.variant), in one process so that all numbers share one clock state.  Prints the
 workgroup count of each choice and marks the fastest: the data behind the automatic choice in rc_launch_draw.
-    python tools/p_sweep.py [ref|ext] [count,count,...]"""
+    python tools/p_sweep.py [ref|ext] [count,count,...]      (P_SWEEP_TUNING=<rc_opts.tuning bits> for every launch)"""
 import ctypes as C, os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from cudaraytracing_amd import abi, configs
 from cudaraytracing_amd.host import Camera, DeviceBuffer, generate_scene
 
 shading = sys.argv[1] if len(sys.argv) > 1 else "ref"
+tuning = int(os.environ.get("P_SWEEP_TUNING", "0"), 0)
 # (width, rows rendered, height of the whole frame, first row): the last two are row bands of a 7680x4320 frame (one of 16
 # and one of 8, from the middle, where the spheres are), rendered as bands -- the camera sees the whole frame
 formats = [(640, 480, 480, 0), (1280, 768, 768, 0), (1920, 1080, 1080, 0), (2560, 1440, 1440, 0), (3840, 1080, 1080, 0),
@@ -32,7 +33,7 @@ for n in counts:
         screen = abi.RcScreen(surf.ptr.value, w, h, w * 16)
         row = []
         for name, v, p in variants:
-            opts = abi.RcOpts(variant=v, y_offset=y0, full_height=full_h)
+            opts = abi.RcOpts(variant=v, y_offset=y0, full_height=full_h, tuning=tuning)
             if shading == "ext":
                 opts.mode = abi.MODE_EXT; opts.ext = C.pointer(ext)
             est = max(1, int(0.06 / (1e-12 * w * h * max(n, 8) / 25)))
@@ -45,7 +46,7 @@ for n in counts:
             ms = C.c_float(); lib.rc_event_elapsed_ms(e0, e1, C.byref(ms))
             tiles = ((w + 16 * p - 1) // (16 * p)) * ((h + 15) // 16)
             row.append((name, tiles, ms.value / reps))
-        opts = abi.RcOpts(variant=abi.VARIANT_AUTO, y_offset=y0, full_height=full_h)
+        opts = abi.RcOpts(variant=abi.VARIANT_AUTO, y_offset=y0, full_height=full_h, tuning=tuning)
         if shading == "ext":
             opts.mode = abi.MODE_EXT; opts.ext = C.pointer(ext)
         for _ in range(reps): lib.rc_render(C.byref(screen), C.byref(scene), C.byref(opts))
