@@ -1602,7 +1602,7 @@ static long long rc_tile_count(const RcKernArgs &a)
 }
 
 template <int P>
-static hipError_t rc_launch_tiled(RcKernArgs a, hipStream_t stream)
+static hipError_t rc_launch_tiled(RcKernArgs a, int compute_units, hipStream_t stream)
 {
     // LDS chunk: the whole scene when it fits (rounded up to whole blocks of kBlockSpheres)
     const int n16 = ((a.n > 0 ? a.n : 1) + kBlockSpheres - 1) & ~(kBlockSpheres - 1);
@@ -1613,6 +1613,12 @@ static hipError_t rc_launch_tiled(RcKernArgs a, hipStream_t stream)
     // 1280x768 x 4096 0.228 vs 0.257 ms, neutral at 2048 spheres.  EXT gains only on frames with many
     // workgroups (3840x2160 x 4096: 2.67 vs 2.85 ms; 1920x1080 x 4096: 1.03 vs 0.97 ms).
     if (a.n > 2048 && !a.cull && (!a.ext_mode || rc_tile_count<P>(a) >= 4096)) a.lds_cap = RC_LDS_EXACT_MAX;
+    // The REF kernels with 4 and 2 pixels per lane fit 5 and 7 waves per SIMD by their registers; passes of 960 / 672
+    // spheres (31.7 / 22.2 KB with the exact-test terms) let as many workgroups share the CU's 160 KB of LDS where
+    // the frame has them.  1920x1080 x 4096: 0.366 -> 0.359 ms; 1280x768 x 1024 / 2048 / 4096: 0.0615 -> 0.0596,
+    // 0.120 -> 0.113, 0.228 -> 0.221 ms (at 640x480, two workgroups per CU, the shorter passes only cost: unchanged).
+    if (!a.cull && !a.ext_mode && P == 4 && a.n > 2048) a.lds_cap = 960;
+    if (!a.cull && !a.ext_mode && P == 2 && a.n > 672 && rc_tile_count<P>(a) > 4LL * compute_units) a.lds_cap = 672;
     // The culled variant is latency-bound while it builds its records, so it wants many
     // resident workgroups: 1024-sphere passes (17 KB of LDS) measured 1.5x faster at
     // 7680x4320 x 4096 spheres than one 4096-sphere pass (62 KB, two workgroups per CU).
@@ -1675,9 +1681,9 @@ hipError_t rc_launch_draw(const RcKernArgs &a, int variant, int compute_units, h
         else hipLaunchKernelGGL(rc_draw_literal<false>, grid, dim3(256), 0, stream, a);
         return hipGetLastError();
     }
-    if (variant == RC_KVARIANT_TILED2) return rc_launch_tiled<2>(a, stream);
-    if (variant == RC_KVARIANT_TILED4) return rc_launch_tiled<4>(a, stream);
-    if (variant == RC_KVARIANT_TILED8) return a.ext_mode ? rc_launch_tiled<4>(a, stream) : rc_launch_tiled<8>(a, stream);
+    if (variant == RC_KVARIANT_TILED2) return rc_launch_tiled<2>(a, compute_units, stream);
+    if (variant == RC_KVARIANT_TILED4) return rc_launch_tiled<4>(a, compute_units, stream);
+    if (variant == RC_KVARIANT_TILED8) return a.ext_mode ? rc_launch_tiled<4>(a, compute_units, stream) : rc_launch_tiled<8>(a, compute_units, stream);
     // Automatic: more pixels per lane share more of the per-sphere work, but the frame must still cut into enough
     // workgroups to fill the chip (tools/p_sweep.py: 6 frame formats and 2 row bands of a 7680x4320 frame x 5 sphere
     // counts, each with every choice forced).  REF: 4 pixels per lane from 5 workgroups per CU; 8 from 9 per CU
@@ -1689,15 +1695,15 @@ hipError_t rc_launch_draw(const RcKernArgs &a, int variant, int compute_units, h
     const long long want8 = (a.n >= 1024 ? 7LL : 9LL) * compute_units;
     // EXT keeps shadow-ray state per pixel: at most 4 pixels per lane.  The culled variant
     // prefers small wave tiles (fewer pixels share a visited sphere): 4 at most as well.
-    if (!a.ext_mode && !a.cull && rc_tile_count<8>(a) >= want8) return rc_launch_tiled<8>(a, stream);
+    if (!a.ext_mode && !a.cull && rc_tile_count<8>(a) >= want8) return rc_launch_tiled<8>(a, compute_units, stream);
     // EXT: the 2-pixel kernels run at 5-6 waves per SIMD, the 4-pixel ones at 4, so 4 pixels per lane need more
     // workgroups to pay: above 2048 spheres (several LDS passes) 5 per CU as above; up to 2048 spheres 10 per CU
     // (1920x1080 stays at 2: equal at 1024 spheres, 3 % faster at 2048); below 768 spheres 24 per CU (2560x1440,
     // 3840x1080 and the 7680x540 band are 2-9 % faster with 2 up to 512 spheres, even at 768, 4 % slower at 900;
     // 3840x2160 keeps 4: 4-7 % faster from 256 spheres, 3 % slower at 64).
     const long long want4 = (a.ext_mode && !a.cull && a.n <= 2048) ? (a.n < 768 ? 24LL * compute_units : 2 * want) : want;
-    if (rc_tile_count<4>(a) >= want4) return rc_launch_tiled<4>(a, stream);
-    return rc_launch_tiled<2>(a, stream);
+    if (rc_tile_count<4>(a) >= want4) return rc_launch_tiled<4>(a, compute_units, stream);
+    return rc_launch_tiled<2>(a, compute_units, stream);
 }
 
 hipError_t rc_launch_records(const RcKernArgs &a, float4 *records, hipStream_t stream)

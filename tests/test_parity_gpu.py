@@ -1103,3 +1103,23 @@ def test_extreme_shapes(oracle, w, h, n):
     for variant, ws in [(abi.VARIANT_AUTO, False), (abi.VARIANT_CULLED, True), (abi.VARIANT_LITERAL, False)]:
         got = pixels(gpu_render(pos, rad, col, cam, w, h, variant=variant, workspace=ws), w)
         assert_same_bits(got, want, f"{w}x{h} n={n} variant {variant}")
+
+
+@pytest.mark.parametrize("w,h,n,variant", [(1280, 768, 673, abi.VARIANT_TILED2), (1280, 768, 1024, abi.VARIANT_AUTO),
+                                           (1280, 768, 2100, abi.VARIANT_TILED2), (1296, 771, 4096, abi.VARIANT_AUTO),
+                                           (1920, 1080, 2049, abi.VARIANT_TILED4), (1920, 1080, 4000, abi.VARIANT_AUTO)])
+def test_lds_pass_sizes_on_frames_with_many_workgroups(w, h, n, variant):
+    """The launcher shortens the LDS passes of the 2- and 4-pixel REF kernels (672 / 960 spheres) only on frames
+    that cut into more workgroups than the small test frames do: sphere counts just past a pass, several passes
+    with a ragged last one, against the literal kernel on the device (itself held to the oracle elsewhere)."""
+    rng = np.random.default_rng(n)
+    pos = rng.uniform(-12, 12, (n, 3)).astype(np.float32); pos[:, 2] = rng.uniform(-18, -2, n).astype(np.float32)
+    rad = rng.uniform(0.05, 0.6, n).astype(np.float32)
+    col = rng.uniform(0, 1, (n, 3)).astype(np.float32)
+    from cudaraytracing_amd.host import Camera
+    cam = Camera(w, h); cam.position, cam.rotation = (0.5, -0.25, 20.0), (0.02, -0.03, 0.0)
+    scene = GpuScene(pos, rad, col)
+    want = pixels(gpu_render(pos, rad, col, cam.get_data(), w, h, variant=abi.VARIANT_LITERAL, scene=scene), w)
+    got = pixels(gpu_render(pos, rad, col, cam.get_data(), w, h, variant=variant, scene=scene), w)
+    scene.free()
+    assert_same_bits(got, want, f"{w}x{h} n={n} variant {variant}")
