@@ -61,11 +61,11 @@ def band_rows(height, world, rank):
 
 
 def pixels_per_lane(width, rows, n, ext, culled, compute_units):
-    """Pixels per lane the library's launcher picks for a frame (the rule of rc_launch_draw in csrc/rc_kernels.hip,
-    restated for bench.py and the tools, which price the executed work per test with it)."""
-    tiles = lambda p: -(-width // (16 * p)) * -(-rows // 16)   # noqa: E731
-    want = 5 * compute_units
-    if not ext and not culled and tiles(8) >= (7 if n >= 1024 else 9) * compute_units:
-        return 8
-    want4 = ((24 * compute_units if n < 768 else 2 * want) if (ext and not culled and n <= 2048) else want)
-    return 4 if tiles(4) >= want4 else 2
+    """Pixels per lane the library's launcher picks for a frame: asked of the library itself (rc_pixels_per_lane, the
+    rule rc_launch_draw applies), for bench.py and the tools, which price the executed work per test with it."""
+    from . import abi
+    p = abi.load().rc_pixels_per_lane(width, rows, n, abi.MODE_EXT if ext else abi.MODE_REF,
+                                      abi.VARIANT_CULLED if culled else abi.VARIANT_AUTO, compute_units)
+    if p < 0:
+        raise ValueError(f"rc_pixels_per_lane({width}, {rows}, {n}): error {p}")
+    return p

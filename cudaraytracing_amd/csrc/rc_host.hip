@@ -846,6 +846,26 @@ extern "C" int rc_selftest_math(int which, uint32_t first_bits, uint32_t count, 
     return RC_OK;
 }
 
+extern "C" int rc_pixels_per_lane(int width, int rows, int sphere_num, int mode, int variant, int compute_units)
+{
+    if (width <= 0 || rows <= 0 || sphere_num < 0) return rc_fail_arg("rc_pixels_per_lane: bad frame or sphere count");
+    if (mode != RC_MODE_REF && mode != RC_MODE_EXT) return rc_fail_arg("rc_pixels_per_lane: unknown mode");
+    const bool ext = mode == RC_MODE_EXT;
+    switch (variant) {
+    case RC_VARIANT_LITERAL: return 1;
+    case RC_VARIANT_TILED_P2: return 2;
+    case RC_VARIANT_TILED_P4: return 4;
+    case RC_VARIANT_TILED_P8: return ext ? 4 : 8;
+    case RC_VARIANT_AUTO: case RC_VARIANT_TILED: case RC_VARIANT_CULLED: break;
+    default: return rc_fail_arg("rc_pixels_per_lane: unknown variant");
+    }
+    RcKernArgs a{};
+    a.width = width; a.rows = rows; a.n = sphere_num;
+    a.ext_mode = ext ? 1 : 0;
+    a.cull = variant == RC_VARIANT_CULLED ? 1 : 0;
+    return rc_auto_pixels_per_lane(a, compute_units);
+}
+
 extern "C" const char *rc_last_error_string(void) { return g_err; }
 
 extern "C" const char *rc_version(void) { return "rc_hip 0.2 gfx950"; }

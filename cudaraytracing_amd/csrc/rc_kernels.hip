@@ -1672,6 +1672,33 @@ static hipError_t rc_launch_tiled(RcKernArgs a, int compute_units, hipStream_t s
     return hipGetLastError();
 }
 
+// Pixels per lane of the tiled kernels when the caller leaves the choice to the library (only a.width, a.rows, a.n,
+// a.ext_mode and a.cull are read).
+int rc_auto_pixels_per_lane(const RcKernArgs &a, int compute_units)
+{
+    if (compute_units <= 0) compute_units = 256;
+    // Automatic: more pixels per lane share more of the per-sphere work, but the frame must still cut into enough
+    // workgroups to fill the chip (tools/p_sweep.py: 6 frame formats and 2 row bands of a 7680x4320 frame x 5 sphere
+    // counts, each with every choice forced).  REF: 4 pixels per lane from 5 workgroups per CU; 8 from 9 per CU
+    // (3840x2160 and up) -- and, from 1024 spheres, already from 7 per CU: 2560x1440, 3840x1080 and a 7680x540
+    // band then gain 1-7 % from 8 pixels per lane and lose 3-5 % with fewer spheres.  (With 4 workgroups per CU,
+    // one round, 8 pixels per lane lose 11-16 % at 1920x1080 but win 4 % on a 7680x270 band: no rule on counts
+    // alone gets both, and they stay at 4.)
+    const long long want = 5LL * compute_units;
+    const long long want8 = (a.n >= 1024 ? 7LL : 9LL) * compute_units;
+    // EXT keeps shadow-ray state per pixel: at most 4 pixels per lane.  The culled variant
+    // prefers small wave tiles (fewer pixels share a visited sphere): 4 at most as well.
+    if (!a.ext_mode && !a.cull && rc_tile_count<8>(a) >= want8) return 8;
+    // EXT: the 2-pixel kernels run at 5-6 waves per SIMD, the 4-pixel ones at 4, so 4 pixels per lane need more
+    // workgroups to pay: above 2048 spheres (several LDS passes) 5 per CU as above; up to 2048 spheres 10 per CU
+    // (1920x1080 stays at 2: equal at 1024 spheres, 3 % faster at 2048); below 768 spheres 24 per CU (2560x1440,
+    // 3840x1080 and the 7680x540 band are 2-9 % faster with 2 up to 512 spheres, even at 768, 4 % slower at 900;
+    // 3840x2160 keeps 4: 4-7 % faster from 256 spheres, 3 % slower at 64).
+    const long long want4 = (a.ext_mode && !a.cull && a.n <= 2048) ? (a.n < 768 ? 24LL * compute_units : 2 * want) : want;
+    if (rc_tile_count<4>(a) >= want4) return 4;
+    return 2;
+}
+
 hipError_t rc_launch_draw(const RcKernArgs &a, int variant, int compute_units, hipStream_t stream)
 {
     if (compute_units <= 0) compute_units = 256;
@@ -1684,25 +1711,9 @@ hipError_t rc_launch_draw(const RcKernArgs &a, int variant, int compute_units, h
     if (variant == RC_KVARIANT_TILED2) return rc_launch_tiled<2>(a, compute_units, stream);
     if (variant == RC_KVARIANT_TILED4) return rc_launch_tiled<4>(a, compute_units, stream);
     if (variant == RC_KVARIANT_TILED8) return a.ext_mode ? rc_launch_tiled<4>(a, compute_units, stream) : rc_launch_tiled<8>(a, compute_units, stream);
-    // Automatic: more pixels per lane share more of the per-sphere work, but the frame must still cut into enough
-    // workgroups to fill the chip (tools/p_sweep.py: 6 frame formats and 2 row bands of a 7680x4320 frame x 5 sphere
-    // counts, each with every choice forced).  REF: 4 pixels per lane from 5 workgroups per CU; 8 from 9 per CU
-    // (3840x2160 and up) -- and, from 1024 spheres, already from 7 per CU: 2560x1440, 3840x1080 and a 7680x540
-    // band then gain 1-7 % from 8 pixels per lane and lose 3-5 % with fewer spheres.  (With 4 workgroups per CU,
-    // one round, 8 pixels per lane lose 11-16 % at 1920x1080 but win 4 % on a 7680x270 band: no rule on counts
-    // alone gets both, and they stay at 4.)
-    const long long want = 5LL * compute_units;
-    const long long want8 = (a.n >= 1024 ? 7LL : 9LL) * compute_units;
-    // EXT keeps shadow-ray state per pixel: at most 4 pixels per lane.  The culled variant
-    // prefers small wave tiles (fewer pixels share a visited sphere): 4 at most as well.
-    if (!a.ext_mode && !a.cull && rc_tile_count<8>(a) >= want8) return rc_launch_tiled<8>(a, compute_units, stream);
-    // EXT: the 2-pixel kernels run at 5-6 waves per SIMD, the 4-pixel ones at 4, so 4 pixels per lane need more
-    // workgroups to pay: above 2048 spheres (several LDS passes) 5 per CU as above; up to 2048 spheres 10 per CU
-    // (1920x1080 stays at 2: equal at 1024 spheres, 3 % faster at 2048); below 768 spheres 24 per CU (2560x1440,
-    // 3840x1080 and the 7680x540 band are 2-9 % faster with 2 up to 512 spheres, even at 768, 4 % slower at 900;
-    // 3840x2160 keeps 4: 4-7 % faster from 256 spheres, 3 % slower at 64).
-    const long long want4 = (a.ext_mode && !a.cull && a.n <= 2048) ? (a.n < 768 ? 24LL * compute_units : 2 * want) : want;
-    if (rc_tile_count<4>(a) >= want4) return rc_launch_tiled<4>(a, compute_units, stream);
+    const int p = rc_auto_pixels_per_lane(a, compute_units);
+    if (p == 8) return rc_launch_tiled<8>(a, compute_units, stream);
+    if (p == 4) return rc_launch_tiled<4>(a, compute_units, stream);
     return rc_launch_tiled<2>(a, compute_units, stream);
 }
 

@@ -105,6 +105,28 @@ def test_render_rejects_bad_arguments(rclib):
         assert rclib.rc_render(C.byref(ok), C.byref(scene), C.byref(o)) == abi.RC_EINVAL
 
 
+def test_pixels_per_lane_query(rclib):
+    """rc_pixels_per_lane answers on the host with the launcher's own rule: the measured crossovers of
+    tools/p_sweep.py (profiles/r3_p_sweep_*.txt), forced variants, and bad arguments."""
+    ask = lambda w, rows, n, mode=abi.MODE_REF, variant=abi.VARIANT_AUTO, cu=256: rclib.rc_pixels_per_lane(w, rows, n, mode, variant, cu)  # noqa: E731
+    assert [ask(640, 480, 8), ask(1280, 768, 512), ask(1920, 1080, 64), ask(3840, 2160, 1024), ask(7680, 4320, 4096)] == [2, 2, 4, 8, 8]
+    # 7-8 workgroups per CU at 8 pixels per lane: 8 only from 1024 spheres (a 7680x540 band is configuration 4's per-rank work)
+    assert [ask(7680, 540, 4096), ask(7680, 540, 512), ask(2560, 1440, 1024), ask(2560, 1440, 1023), ask(7680, 270, 4096)] == [8, 4, 8, 4, 4]
+    ext = lambda w, rows, n: ask(w, rows, n, mode=abi.MODE_EXT)  # noqa: E731
+    assert [ext(1920, 1080, 64), ext(3840, 2160, 1024), ext(2560, 1440, 512), ext(2560, 1440, 768), ext(1920, 1080, 2048),
+            ext(1920, 1080, 2049), ext(3840, 2160, 64)] == [2, 4, 2, 4, 2, 4, 4]
+    assert ask(3840, 2160, 1024, variant=abi.VARIANT_CULLED) == 4 and ask(640, 480, 8, variant=abi.VARIANT_CULLED) == 2
+    assert ask(64, 64, 1, variant=abi.VARIANT_LITERAL) == 1 and ask(64, 64, 1, variant=abi.VARIANT_TILED8) == 8
+    assert ask(64, 64, 1, mode=abi.MODE_EXT, variant=abi.VARIANT_TILED8) == 4 and ask(64, 64, 1, variant=abi.VARIANT_TILED2) == 2
+    assert ask(3840, 2160, 1024, cu=0) == ask(3840, 2160, 1024, cu=256)          # 0: the 256 CUs of an MI355X
+    assert ask(3840, 2160, 1024, cu=1024) == 4 and ask(1280, 768, 1024, cu=64) == 8  # the rule scales with the CU count
+    for bad in [(0, 480, 8), (640, 0, 8), (640, 480, -1)]:
+        assert rclib.rc_pixels_per_lane(*bad, abi.MODE_REF, abi.VARIANT_AUTO, 256) == abi.RC_EINVAL
+    assert ask(640, 480, 8, mode=7) == abi.RC_EINVAL and ask(640, 480, 8, variant=99) == abi.RC_EINVAL
+    from cudaraytracing_amd import configs
+    assert configs.pixels_per_lane(3840, 2160, 1024, True, False, 256) == 4
+
+
 def test_write_ppm(rclib, tmp_path):
     img = np.arange(5 * 3 * 4, dtype=np.uint8).reshape(3, 5, 4)
     path = tmp_path / "t.ppm"
