@@ -768,7 +768,10 @@ def main():
     # Literal kernel: kernel.cu:53-58 as written, 21 FLOP to the discriminant.
     cu_count = C.c_int()
     abi.check(lib.rc_device_info(local_rank, C.byref(cu_count), None, None))
-    ppl = configs.pixels_per_lane(w, rows, n, args.shading == "ext", args.variant == "culled", cu_count.value)
+    # (bands mode launches one kernel per piece: the launcher sees a piece's rows and the frame's height)
+    launch_rows = (gatherer.pieces[0][1] - gatherer.pieces[0][0]) if banded else rows
+    ppl = configs.pixels_per_lane(w, launch_rows, n, args.shading == "ext", args.variant == "culled", cu_count.value,
+                                  full_height=h)
     ppl = {"tiled2": 2, "tiled4": 4, "tiled8": 8 if args.shading == "ref" else 4}.get(args.variant, ppl)
     axis = False
     if args.variant == "literal":

@@ -128,7 +128,7 @@ SYMBOLS = {
     "rc_generate_scene": (None, [C.c_uint32, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p]),
     "rc_write_ppm": (C.c_int, [C.c_char_p, C.c_void_p, C.c_size_t, C.c_int, C.c_int]),
     "rc_selftest_math": (C.c_int, [C.c_int, C.c_uint32, C.c_uint32, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
-    "rc_pixels_per_lane": (C.c_int, [C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int]),
+    "rc_pixels_per_lane": (C.c_int, [C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int]),
     "rc_last_error_string": (C.c_char_p, []),
     "rc_version": (C.c_char_p, []),
     "rc_abi_version": (C.c_int, []),

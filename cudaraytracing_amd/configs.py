@@ -60,12 +60,13 @@ def band_rows(height, world, rank):
     return begin, begin + base + (1 if rank < rem else 0)
 
 
-def pixels_per_lane(width, rows, n, ext, culled, compute_units):
-    """Pixels per lane the library's launcher picks for a frame: asked of the library itself (rc_pixels_per_lane, the
-    rule rc_launch_draw applies), for bench.py and the tools, which price the executed work per test with it."""
+def pixels_per_lane(width, rows, n, ext, culled, compute_units, full_height=0):
+    """Pixels per lane the library's launcher picks for `rows` rows of a frame of `full_height` rows (0: the rows are
+    the frame): asked of the library itself (rc_pixels_per_lane, the rule rc_launch_draw applies), for bench.py and
+    the tools, which price the executed work per test with it."""
     from . import abi
-    p = abi.load().rc_pixels_per_lane(width, rows, n, abi.MODE_EXT if ext else abi.MODE_REF,
+    p = abi.load().rc_pixels_per_lane(width, rows, full_height, n, abi.MODE_EXT if ext else abi.MODE_REF,
                                       abi.VARIANT_CULLED if culled else abi.VARIANT_AUTO, compute_units)
     if p < 0:
-        raise ValueError(f"rc_pixels_per_lane({width}, {rows}, {n}): error {p}")
+        raise ValueError(f"rc_pixels_per_lane({width}, {rows}, {full_height}, {n}): error {p}")
     return p

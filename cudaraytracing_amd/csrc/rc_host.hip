@@ -344,7 +344,8 @@ int rc_enqueue_frame(const rc_screen *screen, const rc_scene *scene, const rc_op
             a.bins_bytes = workspace_bytes - rec_bytes;
         }
     }
-    hipError_t e = rc_launch_draw(a, kv, cus, static_cast<hipStream_t>(o.stream));
+    hipError_t e = rc_launch_draw(a, kv, o.full_height > 0 ? o.full_height : screen->height, cus,
+                                  static_cast<hipStream_t>(o.stream));
     if (e != hipSuccess) return rc_fail_hip(e, "draw kernel launch");
     return RC_OK;
 }
@@ -846,9 +847,11 @@ extern "C" int rc_selftest_math(int which, uint32_t first_bits, uint32_t count, 
     return RC_OK;
 }
 
-extern "C" int rc_pixels_per_lane(int width, int rows, int sphere_num, int mode, int variant, int compute_units)
+extern "C" int rc_pixels_per_lane(int width, int rows, int full_height, int sphere_num, int mode, int variant,
+                                  int compute_units)
 {
     if (width <= 0 || rows <= 0 || sphere_num < 0) return rc_fail_arg("rc_pixels_per_lane: bad frame or sphere count");
+    if (full_height != 0 && full_height < rows) return rc_fail_arg("rc_pixels_per_lane: full_height below rows");
     if (mode != RC_MODE_REF && mode != RC_MODE_EXT) return rc_fail_arg("rc_pixels_per_lane: unknown mode");
     const bool ext = mode == RC_MODE_EXT;
     switch (variant) {
@@ -863,7 +866,7 @@ extern "C" int rc_pixels_per_lane(int width, int rows, int sphere_num, int mode,
     a.width = width; a.rows = rows; a.n = sphere_num;
     a.ext_mode = ext ? 1 : 0;
     a.cull = variant == RC_VARIANT_CULLED ? 1 : 0;
-    return rc_auto_pixels_per_lane(a, compute_units);
+    return rc_auto_pixels_per_lane(a, full_height, compute_units);
 }
 
 extern "C" const char *rc_last_error_string(void) { return g_err; }

@@ -72,9 +72,10 @@ struct RcKernArgs {
     int bins_x, bin_q, bin_stride; // bins per row, entries per list segment, bytes per bin
 };
 
-hipError_t rc_launch_draw(const RcKernArgs &a, int variant, int compute_units, hipStream_t stream);
+// full_height: rows of the whole frame (a.rows of them are rendered by this launch)
+hipError_t rc_launch_draw(const RcKernArgs &a, int variant, int full_height, int compute_units, hipStream_t stream);
 // pixels per lane RC_KVARIANT_AUTO resolves to (reads a.width, a.rows, a.n, a.ext_mode, a.cull only)
-int rc_auto_pixels_per_lane(const RcKernArgs &a, int compute_units);
+int rc_auto_pixels_per_lane(const RcKernArgs &a, int full_height, int compute_units);
 // Builds the n filter records of the scene for this camera into `records` (16 bytes each).
 hipError_t rc_launch_records(const RcKernArgs &a, float4 *records, hipStream_t stream);
 hipError_t rc_launch_rgba8(const void *surface, size_t pitch, int width, int rows, void *out,

@@ -1674,18 +1674,23 @@ static hipError_t rc_launch_tiled(RcKernArgs a, int compute_units, hipStream_t s
 
 // Pixels per lane of the tiled kernels when the caller leaves the choice to the library (only a.width, a.rows, a.n,
 // a.ext_mode and a.cull are read).
-int rc_auto_pixels_per_lane(const RcKernArgs &a, int compute_units)
+int rc_auto_pixels_per_lane(const RcKernArgs &a, int full_height, int compute_units)
 {
     if (compute_units <= 0) compute_units = 256;
+    if (full_height < a.rows) full_height = a.rows;
     // Automatic: more pixels per lane share more of the per-sphere work, but the frame must still cut into enough
     // workgroups to fill the chip (tools/p_sweep.py: 6 frame formats and 2 row bands of a 7680x4320 frame x 5 sphere
     // counts, each with every choice forced).  REF: 4 pixels per lane from 5 workgroups per CU; 8 from 9 per CU
     // (3840x2160 and up) -- and, from 1024 spheres, already from 7 per CU: 2560x1440, 3840x1080 and a 7680x540
-    // band then gain 1-7 % from 8 pixels per lane and lose 3-5 % with fewer spheres.  (With 4 workgroups per CU,
-    // one round, 8 pixels per lane lose 11-16 % at 1920x1080 but win 4 % on a 7680x270 band: no rule on counts
-    // alone gets both, and they stay at 4.)
+    // band then gain 1-7 % from 8 pixels per lane and lose 3-5 % with fewer spheres.  With 4 workgroups per CU --
+    // a single round of the 8-pixel kernel, no workgroup left to even out tiles of unequal cost -- 8 pixels per lane
+    // lose 8-16 % on whole frames (1920x1080, 2560x800 of a 1440-row frame), whose top and bottom tiles are cheap
+    // and whose middle ones are not, and win 1-10 % on a band of at most a quarter of the frame's rows, whose tiles
+    // cost about the same (7680x270 of 4320 rows at three heights, 3840x540 of 2160 at two, 1920x1080 of 4320; one
+    // of six shapes, 5120x400 of 2880, loses 2 % at 4096 spheres).
     const long long want = 5LL * compute_units;
-    const long long want8 = (a.n >= 1024 ? 7LL : 9LL) * compute_units;
+    long long want8 = (a.n >= 1024 ? 7LL : 9LL) * compute_units;
+    if (a.n >= 1024 && 4LL * a.rows <= full_height) want8 = 4LL * compute_units - compute_units / 8;
     // EXT keeps shadow-ray state per pixel: at most 4 pixels per lane.  The culled variant
     // prefers small wave tiles (fewer pixels share a visited sphere): 4 at most as well.
     if (!a.ext_mode && !a.cull && rc_tile_count<8>(a) >= want8) return 8;
@@ -1699,7 +1704,7 @@ int rc_auto_pixels_per_lane(const RcKernArgs &a, int compute_units)
     return 2;
 }
 
-hipError_t rc_launch_draw(const RcKernArgs &a, int variant, int compute_units, hipStream_t stream)
+hipError_t rc_launch_draw(const RcKernArgs &a, int variant, int full_height, int compute_units, hipStream_t stream)
 {
     if (compute_units <= 0) compute_units = 256;
     if (variant == RC_KVARIANT_LITERAL) {
@@ -1711,7 +1716,7 @@ hipError_t rc_launch_draw(const RcKernArgs &a, int variant, int compute_units, h
     if (variant == RC_KVARIANT_TILED2) return rc_launch_tiled<2>(a, compute_units, stream);
     if (variant == RC_KVARIANT_TILED4) return rc_launch_tiled<4>(a, compute_units, stream);
     if (variant == RC_KVARIANT_TILED8) return a.ext_mode ? rc_launch_tiled<4>(a, compute_units, stream) : rc_launch_tiled<8>(a, compute_units, stream);
-    const int p = rc_auto_pixels_per_lane(a, compute_units);
+    const int p = rc_auto_pixels_per_lane(a, full_height, compute_units);
     if (p == 8) return rc_launch_tiled<8>(a, compute_units, stream);
     if (p == 4) return rc_launch_tiled<4>(a, compute_units, stream);
     return rc_launch_tiled<2>(a, compute_units, stream);

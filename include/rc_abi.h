@@ -316,12 +316,12 @@ int rc_ctx_write_ppm(rc_ctx *ctx, const char *path);
 const rc_screen *rc_ctx_screen(const rc_ctx *ctx);
 const rc_scene *rc_ctx_scene(const rc_ctx *ctx);
 
-/* Pixels per lane (1, 2, 4 or 8) of the kernel rc_render launches for a frame of `rows` rows rendered in one call
- * (a band's rows, not the whole frame's), or a negative code.  The reference's launch shape is fixed, one pixel per
+/* Pixels per lane (1, 2, 4 or 8) of the kernel rc_render launches for `rows` rows rendered in one call (a band's
+ * rows; full_height: the whole frame's, as in rc_opts, 0 = rows), or a negative code.  The reference's launch shape is fixed, one pixel per
  * thread in 32 x 16 blocks (kernel.cu:120-123); here it depends on the frame, the sphere count and the CU count
  * (0: 256), and callers that price the executed work or name the kernel in a profile need to know it.  Host only: no
  * device is touched. */
-int rc_pixels_per_lane(int width, int rows, int sphere_num, int mode, int variant, int compute_units);
+int rc_pixels_per_lane(int width, int rows, int full_height, int sphere_num, int mode, int variant, int compute_units);
 
 /* Diagnostic, no counterpart in the reference.  The kernels evaluate some correctly rounded square roots and
  * reciprocals (vec3::norm, vec3.h:168-176,89-92) with sequences shorter than the compiler's general ones, valid for

@@ -108,7 +108,7 @@ def test_render_rejects_bad_arguments(rclib):
 def test_pixels_per_lane_query(rclib):
     """rc_pixels_per_lane answers on the host with the launcher's own rule: the measured crossovers of
     tools/p_sweep.py (profiles/r3_p_sweep_*.txt), forced variants, and bad arguments."""
-    ask = lambda w, rows, n, mode=abi.MODE_REF, variant=abi.VARIANT_AUTO, cu=256: rclib.rc_pixels_per_lane(w, rows, n, mode, variant, cu)  # noqa: E731
+    ask = lambda w, rows, n, mode=abi.MODE_REF, variant=abi.VARIANT_AUTO, cu=256, full=0: rclib.rc_pixels_per_lane(w, rows, full, n, mode, variant, cu)  # noqa: E731
     assert [ask(640, 480, 8), ask(1280, 768, 512), ask(1920, 1080, 64), ask(3840, 2160, 1024), ask(7680, 4320, 4096)] == [2, 2, 4, 8, 8]
     # 7-8 workgroups per CU at 8 pixels per lane: 8 only from 1024 spheres (a 7680x540 band is configuration 4's per-rank work)
     assert [ask(7680, 540, 4096), ask(7680, 540, 512), ask(2560, 1440, 1024), ask(2560, 1440, 1023), ask(7680, 270, 4096)] == [8, 4, 8, 4, 4]
@@ -120,7 +120,10 @@ def test_pixels_per_lane_query(rclib):
     assert ask(64, 64, 1, mode=abi.MODE_EXT, variant=abi.VARIANT_TILED8) == 4 and ask(64, 64, 1, variant=abi.VARIANT_TILED2) == 2
     assert ask(3840, 2160, 1024, cu=0) == ask(3840, 2160, 1024, cu=256)          # 0: the 256 CUs of an MI355X
     assert ask(3840, 2160, 1024, cu=1024) == 4 and ask(1280, 768, 1024, cu=64) == 8  # the rule scales with the CU count
-    for bad in [(0, 480, 8), (640, 0, 8), (640, 480, -1)]:
+    # a band of at most a quarter of the frame's rows takes 8 pixels per lane from 4 workgroups per CU (>= 1024 spheres)
+    assert [ask(7680, 270, 4096, full=4320), ask(7680, 270, 1023, full=4320), ask(1920, 1080, 4096, full=4320),
+            ask(2560, 800, 4096, full=1440), ask(7680, 270, 4096, full=270), ask(3840, 540, 1024, full=2160)] == [8, 4, 8, 4, 4, 8]
+    for bad in [(0, 480, 0, 8), (640, 0, 0, 8), (640, 480, 0, -1), (640, 480, 479, 8)]:
         assert rclib.rc_pixels_per_lane(*bad, abi.MODE_REF, abi.VARIANT_AUTO, 256) == abi.RC_EINVAL
     assert ask(640, 480, 8, mode=7) == abi.RC_EINVAL and ask(640, 480, 8, variant=99) == abi.RC_EINVAL
     from cudaraytracing_amd import configs

@@ -13,6 +13,8 @@ tuning = int(os.environ.get("P_SWEEP_TUNING", "0"), 0)
 # and one of 8, from the middle, where the spheres are), rendered as bands -- the camera sees the whole frame
 formats = [(640, 480, 480, 0), (1280, 768, 768, 0), (1920, 1080, 1080, 0), (2560, 1440, 1440, 0), (3840, 1080, 1080, 0),
            (3840, 2160, 2160, 0), (7680, 270, 4320, 2160), (7680, 540, 4320, 2160)]
+if os.environ.get("P_SWEEP_FORMATS"):      # "width,rows,frame height,first row;..." replaces the list above
+    formats = [tuple(int(v) for v in f.split(",")) for f in os.environ["P_SWEEP_FORMATS"].split(";")]
 counts = [int(c) for c in sys.argv[2].split(",")] if len(sys.argv) > 2 else [16, 64, 256, 1024, 4096]
 variants = [("P2", abi.VARIANT_TILED2, 2), ("P4", abi.VARIANT_TILED4, 4)] + ([("P8", abi.VARIANT_TILED8, 8)] if shading == "ref" else [])
 lib = abi.load()
@@ -57,7 +59,7 @@ for n in counts:
         ms = C.c_float(); lib.rc_event_elapsed_ms(e0, e1, C.byref(ms))
         best = min(row, key=lambda r: r[2])
         cells = "  ".join(f"{nm} {t:6d} wg {m:8.4f} ms{'*' if nm == best[0] else ' '}" for nm, t, m in row)
-        shape = f"{w}x{h}" + (f" of {full_h}" if full_h != h else "")
-        print(f"n={n:5d} {shape:>17s} {cells}  auto {ms.value / reps:8.4f} ms ({ms.value / reps / best[2]:.3f} x best)", flush=True)
+        shape = f"{w}x{h}" + (f" of {full_h}@{y0}" if full_h != h else "")
+        print(f"n={n:5d} {shape:>22s} {cells}  auto {ms.value / reps:8.4f} ms ({ms.value / reps / best[2]:.3f} x best)", flush=True)
     for b in bufs:
         b.free()
